@@ -1,0 +1,154 @@
+/* playsnark_hip.h -- C ABI of the MI355X-native prover hot path for nikkolasg/playsnark.
+ *
+ * The reference is a single Go package with no FFI; this header is the boundary a cgo shim
+ * binds (INTEGRATION.md shows the shim).  Each entry point names the reference function it
+ * replaces (file:line under /root/reference).  Plain pointers and sizes only; all host
+ * buffers are caller-owned and never retained past return (cgo pointer rules); handles are
+ * opaque, library-owned and explicitly destroyed.  Functions return 0 or a negative
+ * PS_ERR_*; nothing aborts or throws across the boundary.  A ps_ctx is not thread-safe;
+ * distinct contexts are.
+ *
+ * Byte formats (big-endian, what kyber's MarshalBinary produces [upstream]):
+ *   scalar      32 B canonical Fr element
+ *   PS_FMT_AFFINE      G1 96 B  x||y ;  G2 192 B  x_c1||x_c0||y_c1||y_c0 ; identity = 0x40,0,0,...
+ *   PS_FMT_COMPRESSED  G1 48 B / G2 96 B ZCash compressed (flags 0x80 | 0x40 inf | 0x20 sign)
+ * Outputs are always PS_FMT_AFFINE unless stated.
+ */
+#ifndef PLAYSNARK_HIP_H
+#define PLAYSNARK_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK 0
+#define PS_ERR_LENGTH (-1)        /* algebra.go:350-352 panic "mismatch of length between poly ..." */
+#define PS_ERR_NOT_DIVISIBLE (-2) /* qap.go:158-160, pinochio.go:214-216 panic("apocalypse")        */
+#define PS_ERR_ENCODING (-3)      /* non-canonical field element / point not on the curve           */
+#define PS_ERR_HIP (-4)           /* HIP runtime failure; see ps_last_error()                        */
+#define PS_ERR_ARG (-5)           /* NULL handle, unsupported size, sanityCheck (qap.go:177-189)    */
+#define PS_ERR_NO_DEVICE (-6)     /* no gfx950 device visible: the library has no CPU fallback      */
+
+#define PS_FMT_AFFINE 0
+#define PS_FMT_COMPRESSED 1
+
+#define PS_G1 1
+#define PS_G2 2
+
+typedef struct ps_ctx ps_ctx;         /* one device + stream + workspace                       */
+typedef struct ps_points ps_points;   /* device-resident point vector (a CRS array)            */
+typedef struct ps_scalars ps_scalars; /* device-resident Fr vector                             */
+typedef struct ps_qap ps_qap;         /* device-resident sparse QAP + per-n tables             */
+
+const char* ps_last_error(void);
+const char* ps_version(void);
+int ps_device_count(void);
+
+/* ---- context ---- */
+int ps_ctx_create(int device, ps_ctx** out);
+void ps_ctx_destroy(ps_ctx* ctx);
+int ps_ctx_sync(ps_ctx* ctx);
+/* Raw HIP stream of the context (hipStream_t as void*), for callers that time with events. */
+void* ps_ctx_stream(ps_ctx* ctx);
+
+/* ---- CRS / evaluation-key arrays: the []G1 / []G2 slices of Groth16Setup
+ *      (groth16.go:30-61: Xi, Xi2, NioLP, XiT) and PHGR13EvalKey (pinochio.go:37-62) ---- */
+int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts, size_t n, int fmt,
+                     ps_points** out);
+/* out[i] = scalars[i] * G (fixed base).  GeneratePowersCommit (algebra.go:371-384) and the
+ * commit loops of fullLinearPoly (groth16.go:254-264) / generateEvalCommit (pinochio.go:381-388)
+ * reduce to this once the exponents are known. */
+int ps_points_from_scalars(ps_ctx* ctx, int group, const ps_scalars* k, ps_points** out);
+int ps_points_download(ps_ctx* ctx, const ps_points* p, size_t first, size_t n, uint8_t* out);
+size_t ps_points_len(const ps_points* p);
+int ps_points_group(const ps_points* p);
+/* A view of [first, first+n) sharing storage with `p` (index-range sharding, multi-GPU). */
+int ps_points_slice(const ps_points* p, size_t first, size_t n, ps_points** out);
+void ps_points_free(ps_points* p);
+
+/* ---- scalar vectors: Poly = []Element (algebra.go:89) / Vector = []Value (algebra.go:13) ---- */
+int ps_scalars_upload(ps_ctx* ctx, const uint8_t* be32, size_t n, ps_scalars** out);
+/* Value.ToFieldElement = SetInt64 (curve.go:17-19): negatives map to r - |v|. */
+int ps_scalars_upload_i64(ps_ctx* ctx, const int64_t* v, size_t n, ps_scalars** out);
+/* Wrap n big-endian 32-byte scalars already resident in device memory (e.g. a torch tensor's
+ * data_ptr()); the bytes are converted into a library-owned vector. */
+int ps_scalars_from_device_be32(ps_ctx* ctx, const void* d_be32, size_t n, ps_scalars** out);
+int ps_scalars_download(ps_ctx* ctx, const ps_scalars* s, size_t first, size_t n, uint8_t* out_be32);
+size_t ps_scalars_len(const ps_scalars* s);
+int ps_scalars_slice(const ps_scalars* s, size_t first, size_t n, ps_scalars** out);
+void ps_scalars_free(ps_scalars* s);
+
+/* ---- MSM: Poly.BlindEval (algebra.go:348-359), sumBlind (groth16.go:134-141), the NioLP loop
+ *      (groth16.go:173-179), computeSolCommit (pinochio.go:222-229) ----
+ * out = sum_i scalars[i] * points[i].  len(scalars) != len(points) returns PS_ERR_LENGTH, the
+ * reference's panic at algebra.go:350-352.  `out` is 96 B (G1) or 192 B (G2), affine. */
+int ps_msm(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars, uint8_t* out);
+/* Host-buffer convenience forms (upload + ps_msm). */
+int ps_msm_be32(ps_ctx* ctx, const ps_points* points, const uint8_t* scalars_be32, size_t n, uint8_t* out);
+int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, size_t n, uint8_t* out);
+/* Asynchronous form for benchmarking and multi-MSM overlap: launches on the context stream and
+ * leaves the per-window sums on the device; ps_msm_finish() waits and folds them on the host. */
+int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
+int ps_msm_finish(ps_ctx* ctx, uint8_t* out);
+/* Sum of k affine points (the per-GPU partial sums of a sharded MSM, after the RCCL gather). */
+int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* out);
+/* Tuning / introspection of the last MSM on this context. */
+typedef struct {
+    int window_bits;   /* c */
+    int windows;       /* W */
+    uint64_t entries;  /* non-zero digits = bucket additions issued */
+    uint64_t buckets;  /* W * 2^(c-1) */
+    int slice;         /* sorted entries per accumulation thread */
+} ps_msm_info;
+int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
+int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic */);
+
+/* ---- QAP quotient: QAP.Quotient (qap.go:151-162) + computeAggregatePoly (qap.go:164-175) ----
+ * The R1CS matrices (r1cs.go:78-101: rows = gates, columns = variables) are given in CSR with
+ * int64 coefficients (the reference's Value = int, algebra.go:11).  The QAP domain is the
+ * reference's {1..n} (qap.go:42-55, algebra.go:256-258). */
+typedef struct {
+    const uint32_t* row_ptr; /* n+1 */
+    const uint32_t* col;     /* nnz */
+    const int64_t* val;      /* nnz */
+} ps_csr;
+int ps_qap_create(ps_ctx* ctx, size_t n_gates, size_t n_vars, size_t n_io, const ps_csr* L, const ps_csr* R,
+                  const ps_csr* O, ps_qap** out);
+void ps_qap_free(ps_qap* q);
+/* sol: n_vars scalars.  Outputs (any may be NULL): A, B, C aggregate polynomials (n coefficients
+ * each) and h (n-1 coefficients), all device-resident.  PS_ERR_NOT_DIVISIBLE <=> "apocalypse". */
+int ps_qap_quotient(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, ps_scalars** A, ps_scalars** B,
+                    ps_scalars** C, ps_scalars** h);
+
+/* ---- whole-function drivers ---- */
+typedef struct { /* the prover's part of Groth16Setup (groth16.go:30-61) */
+    uint8_t alpha[96], beta[96], delta[96]; /* G1 */
+    uint8_t beta2[192], delta2[192];        /* G2 */
+    const ps_points* xi;                    /* n   G1 */
+    const ps_points* xi2;                   /* n   G2 (declared []G1 at groth16.go:60) */
+    const ps_points* nio_lp;                /* n_vars - (n_vars - n_io) ... see `diff` note */
+    const ps_points* xi_t;                  /* n-1 G1 */
+} ps_groth16_pk;
+/* Groth16Prove (groth16.go:122-211).  r, s are inputs (the reference draws them at :148,:158 and
+ * keeps them in the proof, :203-206).  diff = n_vars - n_io is used as the first non-IO index
+ * exactly as the reference does (groth16.go:175-177). */
+int ps_groth16_prove(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, const ps_scalars* sol,
+                     const uint8_t r_be32[32], const uint8_t s_be32[32], uint8_t A[96], uint8_t B[192],
+                     uint8_t C[96]);
+
+typedef struct { /* PHGR13EvalKey (pinochio.go:37-62); ws is G2, every other array is G1 */
+    const ps_points *vs, *ws, *ys, *vas, *was, *yas, *gsi, *vbs, *wbs, *ybs;
+} ps_phgr13_ek;
+typedef struct { /* PHGR13Proof (pinochio.go:180-203) */
+    uint8_t vss[96], vass[96], wss[192], wass[96], yss[96], yass[96], hs[96], gz[96];
+} ps_phgr13_proof;
+/* PHGR13Prove (pinochio.go:207-254). */
+int ps_phgr13_prove(ps_ctx* ctx, const ps_phgr13_ek* ek, const ps_qap* q, const ps_scalars* sol,
+                    ps_phgr13_proof* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

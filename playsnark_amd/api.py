@@ -1,0 +1,367 @@
+"""Python host mirror of the reference's Go surface for the prover hot path.
+
+Same names, argument meaning and error behaviour as the reference, bound to the C ABI:
+
+    Poly.BlindEval(zero, blindedPoint)   algebra.go:348-359  -> Poly.BlindEval(points)
+    QAP.Quotient(sol)                    qap.go:151-162      -> QAP.Quotient(sol)
+    Groth16Prove(tr, q, sol)             groth16.go:122-211  -> Groth16Prove(tr, q, sol, r, s)
+    PHGR13Prove(ek, qap, solution)       pinochio.go:207-254 -> PHGR13Prove(ek, qap, solution)
+
+The reference signals errors by panicking; here the same conditions raise
+`LengthMismatch` (message of algebra.go:351) and `Apocalypse` ("apocalypse", qap.go:159).
+No arithmetic happens in this file: everything is a call into libplaysnark_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+from . import _lib
+from ._lib import PS_G1, PS_G2, lib
+
+G1, G2 = PS_G1, PS_G2
+_WIRE = {PS_G1: 96, PS_G2: 192}
+
+
+class PlaysnarkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"playsnark_hip error {code}: {msg}")
+        self.code = code
+
+
+class LengthMismatch(ValueError):
+    """panic(fmt.Sprintf("mismatch of length between poly %d and blinded eval points %d")) algebra.go:351"""
+
+
+class Apocalypse(ArithmeticError):
+    """panic("apocalypse") qap.go:159 / pinochio.go:215: the witness does not satisfy the QAP."""
+
+
+def _check(rc: int):
+    if rc == _lib.PS_OK:
+        return
+    msg = (lib.ps_last_error() or b"").decode()
+    if rc == _lib.PS_ERR_LENGTH:
+        raise LengthMismatch(msg)
+    if rc == _lib.PS_ERR_NOT_DIVISIBLE:
+        raise Apocalypse("apocalypse")
+    raise PlaysnarkError(rc, msg)
+
+
+def device_count() -> int:
+    return lib.ps_device_count()
+
+
+class Context:
+    """One GPU + stream + workspace (ps_ctx)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        _check(lib.ps_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def sync(self):
+        _check(lib.ps_ctx_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return lib.ps_ctx_stream(self._h)
+
+    def set_window(self, bits: int):
+        _check(lib.ps_msm_set_window(self._h, bits))
+
+    def last_msm_info(self) -> dict:
+        info = _lib.MsmInfo()
+        _check(lib.ps_msm_last_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.ps_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Points:
+    """A device-resident []G1 / []G2 slice (ps_points), e.g. Groth16Setup.Xi (groth16.go:43)."""
+
+    def __init__(self, ctx: Context, handle, owner=None):
+        self.ctx, self._h, self._owner = ctx, handle, owner
+
+    @classmethod
+    def upload(cls, ctx: Context, group: int, raw: bytes, fmt: int = _lib.PS_FMT_AFFINE) -> "Points":
+        wb = _WIRE[group] if fmt == _lib.PS_FMT_AFFINE else _WIRE[group] // 2
+        assert len(raw) % wb == 0
+        h = C.c_void_p()
+        _check(lib.ps_points_upload(ctx._h, group, raw, len(raw) // wb, fmt, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_scalars(cls, ctx: Context, group: int, k: "Poly") -> "Points":
+        """out[i] = k[i] * G: the commit loop of GeneratePowersCommit (algebra.go:371-384)."""
+        h = C.c_void_p()
+        _check(lib.ps_points_from_scalars(ctx._h, group, k._h, C.byref(h)))
+        return cls(ctx, h)
+
+    @property
+    def group(self) -> int:
+        return lib.ps_points_group(self._h)
+
+    def __len__(self):
+        return lib.ps_points_len(self._h)
+
+    def download(self, first: int = 0, n: Optional[int] = None) -> bytes:
+        n = len(self) - first if n is None else n
+        buf = C.create_string_buffer(_WIRE[self.group] * max(n, 1))
+        _check(lib.ps_points_download(self.ctx._h, self._h, first, n, buf))
+        return buf.raw[: _WIRE[self.group] * n]
+
+    def slice(self, first: int, n: int) -> "Points":
+        h = C.c_void_p()
+        _check(lib.ps_points_slice(self._h, first, n, C.byref(h)))
+        return Points(self.ctx, h, owner=self)
+
+    def free(self):
+        if self._h:
+            lib.ps_points_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _be32(v: int) -> bytes:
+    return int(v).to_bytes(32, "big")
+
+
+class Poly:
+    """type Poly []Element (algebra.go:89), device-resident (ps_scalars).  Also stands in for
+    Vector = []Value (algebra.go:13) through from_values (Value.ToFieldElement, curve.go:17-19)."""
+
+    def __init__(self, ctx: Context, handle, owner=None):
+        self.ctx, self._h, self._owner = ctx, handle, owner
+
+    @classmethod
+    def upload(cls, ctx: Context, coeffs) -> "Poly":
+        raw = coeffs if isinstance(coeffs, (bytes, bytearray)) else b"".join(_be32(c) for c in coeffs)
+        h = C.c_void_p()
+        _check(lib.ps_scalars_upload(ctx._h, bytes(raw), len(raw) // 32, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_values(cls, ctx: Context, values: Sequence[int]) -> "Poly":
+        arr = (C.c_int64 * len(values))(*values)
+        h = C.c_void_p()
+        _check(lib.ps_scalars_upload_i64(ctx._h, arr, len(values), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device_be32(cls, ctx: Context, device_ptr: int, n: int) -> "Poly":
+        h = C.c_void_p()
+        _check(lib.ps_scalars_from_device_be32(ctx._h, C.c_void_p(device_ptr), n, C.byref(h)))
+        return cls(ctx, h)
+
+    def __len__(self):
+        return lib.ps_scalars_len(self._h)
+
+    def download_bytes(self, first: int = 0, n: Optional[int] = None) -> bytes:
+        n = len(self) - first if n is None else n
+        buf = C.create_string_buffer(32 * max(n, 1))
+        _check(lib.ps_scalars_download(self.ctx._h, self._h, first, n, buf))
+        return buf.raw[: 32 * n]
+
+    def download(self, first: int = 0, n: Optional[int] = None):
+        raw = self.download_bytes(first, n)
+        return [int.from_bytes(raw[i : i + 32], "big") for i in range(0, len(raw), 32)]
+
+    def slice(self, first: int, n: int) -> "Poly":
+        h = C.c_void_p()
+        _check(lib.ps_scalars_slice(self._h, first, n, C.byref(h)))
+        return Poly(self.ctx, h, owner=self)
+
+    def BlindEval(self, blindedPoint: Points) -> bytes:
+        """func (p Poly) BlindEval(zero Commit, blindedPoint []Commit) Commit (algebra.go:348).
+        The group is the dynamic type of the points, as in the reference;
+        `zero` is implied.  Returns the affine big-endian point (96 B G1 / 192 B G2)."""
+        out = C.create_string_buffer(_WIRE[blindedPoint.group])
+        _check(lib.ps_msm(self.ctx._h, blindedPoint._h, self._h, out))
+        return out.raw
+
+    def free(self):
+        if self._h:
+            lib.ps_scalars_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_launch(ctx: Context, points: Points, scalars: Poly):
+    """Asynchronous BlindEval: enqueue on the context stream (ps_msm_launch)."""
+    _check(lib.ps_msm_launch(ctx._h, points._h, scalars._h))
+
+
+def msm_finish(ctx: Context, group: int) -> bytes:
+    out = C.create_string_buffer(_WIRE[group])
+    _check(lib.ps_msm_finish(ctx._h, out))
+    return out.raw
+
+
+def points_sum(group: int, raw: bytes) -> bytes:
+    """Sum of affine points: folds the per-GPU partial sums after the RCCL gather."""
+    out = C.create_string_buffer(_WIRE[group])
+    _check(lib.ps_points_sum(group, raw, len(raw) // _WIRE[group], out))
+    return out.raw
+
+
+# -----------------------------------------------------------------------------------------
+# QAP / provers
+# -----------------------------------------------------------------------------------------
+def _csr(rows: Sequence[Sequence[tuple]]):
+    """rows[g] = [(col, int_value), ...] -> (Csr struct, keep-alive arrays)."""
+    row_ptr = [0]
+    cols, vals = [], []
+    for r in rows:
+        for col, v in r:
+            if v != 0:
+                cols.append(col)
+                vals.append(v)
+        row_ptr.append(len(cols))
+    a = (C.c_uint32 * len(row_ptr))(*row_ptr)
+    b = (C.c_uint32 * max(len(cols), 1))(*cols)
+    c = (C.c_int64 * max(len(vals), 1))(*vals)
+    s = _lib.Csr(C.cast(a, C.c_void_p), C.cast(b, C.c_void_p), C.cast(c, C.c_void_p))
+    return s, (a, b, c)
+
+
+def dense_to_rows(m: Sequence[Sequence[int]]):
+    return [[(j, v) for j, v in enumerate(row) if v != 0] for row in m]
+
+
+class QAP:
+    """type QAP (qap.go:10-27), kept in the sparse evaluation form the hot path needs: the three
+    R1CS matrices in CSR (rows = gates) on the reference's domain {1..n}."""
+
+    def __init__(self, ctx: Context, nbVars: int, nbIO: int, left_rows, right_rows, out_rows):
+        self.ctx = ctx
+        self.nbVars, self.nbIO, self.nbGates = nbVars, nbIO, len(left_rows)
+        keep = []
+        structs = []
+        for rows in (left_rows, right_rows, out_rows):
+            s, k = _csr(rows)
+            structs.append(s)
+            keep.append(k)
+        h = C.c_void_p()
+        _check(lib.ps_qap_create(ctx._h, self.nbGates, nbVars, nbIO, C.byref(structs[0]), C.byref(structs[1]),
+                                 C.byref(structs[2]), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_dense(cls, ctx: Context, nbVars: int, nbIO: int, left, right, out) -> "QAP":
+        """ToQAP(circuit R1CS) (qap.go:35) from the dense matrices of r1cs.go:99-101."""
+        return cls(ctx, nbVars, nbIO, dense_to_rows(left), dense_to_rows(right), dense_to_rows(out))
+
+    def computeAggregatePoly(self, sol: Poly):
+        """(left, right, out Poly) of qap.go:164-175 plus h in one pass."""
+        hs = [C.c_void_p() for _ in range(4)]
+        _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, *[C.byref(h) for h in hs]))
+        return tuple(Poly(self.ctx, h) for h in hs)
+
+    def Quotient(self, sol: Poly) -> Poly:
+        """func (q QAP) Quotient(sol Vector) Poly (qap.go:151): raises Apocalypse when the
+        remainder is non-zero."""
+        h = C.c_void_p()
+        _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, None, None, None, C.byref(h)))
+        return Poly(self.ctx, h)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib.ps_qap_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Groth16Setup:
+    """The prover's part of type Groth16Setup (groth16.go:30-61)."""
+
+    def __init__(self, Alpha: bytes, Beta: bytes, Delta: bytes, Beta2: bytes, Delta2: bytes, Xi: Points,
+                 Xi2: Points, NioLP: Points, XiT: Points):
+        self.Alpha, self.Beta, self.Delta, self.Beta2, self.Delta2 = Alpha, Beta, Delta, Beta2, Delta2
+        self.Xi, self.Xi2, self.NioLP, self.XiT = Xi, Xi2, NioLP, XiT
+
+    def _struct(self):
+        pk = _lib.Groth16Pk()
+        for name, src in (("alpha", self.Alpha), ("beta", self.Beta), ("delta", self.Delta),
+                          ("beta2", self.Beta2), ("delta2", self.Delta2)):
+            C.memmove(getattr(pk, name), src, len(src))
+        pk.xi, pk.xi2, pk.nio_lp, pk.xi_t = self.Xi._h, self.Xi2._h, self.NioLP._h, self.XiT._h
+        return pk
+
+
+class Groth16Proof:
+    """type Groth16Proof (groth16.go:106-118); tp = (R, S) as supplied."""
+
+    def __init__(self, R, S, A, B, Cc):
+        self.R, self.S, self.A, self.B, self.C = R, S, A, B, Cc
+
+
+def Groth16Prove(tr: Groth16Setup, q: QAP, sol: Poly, r: int, s: int) -> Groth16Proof:
+    """func Groth16Prove(tr Groth16Setup, q QAP, sol Vector) Groth16Proof (groth16.go:122).
+    r and s are drawn by the caller (the reference draws them at :148 and :158)."""
+    A = C.create_string_buffer(96)
+    B = C.create_string_buffer(192)
+    Cc = C.create_string_buffer(96)
+    pk = tr._struct()
+    _check(lib.ps_groth16_prove(q.ctx._h, C.byref(pk), q._h, sol._h, _be32(r), _be32(s), A, B, Cc))
+    return Groth16Proof(r, s, A.raw, B.raw, Cc.raw)
+
+
+class PHGR13EvalKey:
+    """type PHGR13EvalKey (pinochio.go:37-62)."""
+
+    FIELDS = ("vs", "ws", "ys", "vas", "was", "yas", "gsi", "vbs", "wbs", "ybs")
+
+    def __init__(self, **kw):
+        for f in self.FIELDS:
+            setattr(self, f, kw[f])
+
+    def _struct(self):
+        ek = _lib.Phgr13Ek()
+        for f in self.FIELDS:
+            setattr(ek, f, getattr(self, f)._h)
+        return ek
+
+
+class PHGR13Proof:
+    """type PHGR13Proof (pinochio.go:180-203)."""
+
+    FIELDS = ("vss", "vass", "wss", "wass", "yss", "yass", "hs", "gz")
+
+    def __init__(self, raw: _lib.Phgr13Proof):
+        for f in self.FIELDS:
+            setattr(self, f, bytes(getattr(raw, f)))
+
+
+def PHGR13Prove(ek: PHGR13EvalKey, qap: QAP, solution: Poly) -> PHGR13Proof:
+    """func PHGR13Prove(ek PHGR13EvalKey, qap QAP, solution Vector) PHGR13Proof (pinochio.go:207)."""
+    out = _lib.Phgr13Proof()
+    s = ek._struct()
+    _check(lib.ps_phgr13_prove(qap.ctx._h, C.byref(s), qap._h, solution._h, C.byref(out)))
+    return PHGR13Proof(out)

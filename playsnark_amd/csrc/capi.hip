@@ -1,0 +1,583 @@
+// C ABI of libplaysnark_hip.so (include/playsnark_hip.h).  Product code: no CPU fallback --
+// every compute entry point runs the HIP kernels or fails with PS_ERR_NO_DEVICE / PS_ERR_HIP.
+#include "../../include/playsnark_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "msm.cuh"
+#include "quotient.cuh"
+
+using namespace ps;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return fail(PS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+extern "C" const char* ps_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* ps_version(void) { return "playsnark_hip 0.1 (gfx950)"; }
+extern "C" int ps_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return PS_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(PS_ERR_HIP, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+        cap = want;
+        return PS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ps_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // MSM workspace
+    DevBuf counts, offs, bsum, keys, ranks, sorted, buckets, parts, segs, wins;
+    DevBuf staging;                  // byte staging for uploads / downloads
+    DevBuf fb_table[2];              // fixed-base tables (G1, G2)
+    bool fb_ready[2] = {false, false};
+    u32* d_flag = nullptr;           // small device scratch word (bad-point counter etc.)
+    void* h_pinned = nullptr;        // pinned host scratch for window sums
+    size_t h_pinned_cap = 0;
+    // pending async MSM
+    bool pending = false;
+    int pending_group = 0;
+    MsmPlan pending_plan{};
+    ps_msm_info last_info{};
+    int forced_c = 0;
+    QuotientCache* qcache = nullptr;
+};
+
+struct Storage {  // shared device allocation behind slices
+    void* p = nullptr;
+    int refs = 1;
+};
+static void storage_unref(Storage* s) {
+    if (s && --s->refs == 0) {
+        if (s->p) (void)hipFree(s->p);
+        delete s;
+    }
+}
+
+struct ps_points {
+    int group;
+    size_t n;
+    Storage* st;
+    size_t first;  // element offset into the storage
+    int device;
+};
+struct ps_scalars {
+    size_t n;
+    Storage* st;
+    size_t first;
+    int max_bits;  // upper bound on the bit length of every element
+    int device;
+};
+
+static inline size_t point_bytes(int group) { return group == PS_G1 ? sizeof(Affine<Fp>) : sizeof(Affine<Fp2>); }
+static inline size_t wire_bytes(int group) { return group == PS_G1 ? 96 : 192; }
+static inline const void* points_ptr(const ps_points* p) {
+    return (const char*)p->st->p + p->first * point_bytes(p->group);
+}
+static inline const u32* scalars_ptr(const ps_scalars* s) { return (const u32*)s->st->p + 8 * s->first; }
+
+static inline unsigned nblocks(size_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+extern "C" int ps_ctx_create(int device, ps_ctx** out) {
+    if (!out) return fail(PS_ERR_ARG, "ps_ctx_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PS_ERR_NO_DEVICE, "no HIP device visible: playsnark_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(PS_ERR_ARG, "ps_ctx_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(PS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", library is built for gfx950 only");
+    ps_ctx* c = new ps_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&c->d_flag, 64));
+    c->h_pinned_cap = 64 * sizeof(Xyzz<Fp2>) + 64;
+    HIP_TRY(hipHostMalloc(&c->h_pinned, c->h_pinned_cap));
+    *out = c;
+    return PS_OK;
+}
+
+extern "C" void ps_ctx_destroy(ps_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
+                      &c->segs, &c->wins, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+        b->release();
+    quotient_cache_free(c->qcache);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int ps_ctx_sync(ps_ctx* c) {
+    if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PS_OK;
+}
+extern "C" void* ps_ctx_stream(ps_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------------------
+// scalars
+// ---------------------------------------------------------------------------------------
+static int scalars_alloc(ps_ctx* c, size_t n, ps_scalars** out) {
+    Storage* st = new Storage();
+    hipError_t e = hipMalloc(&st->p, std::max<size_t>(32 * n, 32));
+    if (e != hipSuccess) {
+        delete st;
+        return fail(PS_ERR_HIP, std::string("hipMalloc scalars: ") + hipGetErrorString(e));
+    }
+    *out = new ps_scalars{n, st, 0, 255, c->device};
+    return PS_OK;
+}
+
+extern "C" int ps_scalars_from_device_be32(ps_ctx* c, const void* d_be32, size_t n, ps_scalars** out) {
+    if (!c || !out || (n && !d_be32)) return fail(PS_ERR_ARG, "ps_scalars_from_device_be32: NULL argument");
+    if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = scalars_alloc(c, n, out);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_scalars_from_be32, dim3(nblocks(n)), dim3(256), 0, c->stream, (const uint8_t*)d_be32,
+                              (u32)n, (u32*)(*out)->st->p);
+    HIP_TRY(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_scalars_upload(ps_ctx* c, const uint8_t* be32, size_t n, ps_scalars** out) {
+    if (!c || !out || (n && !be32)) return fail(PS_ERR_ARG, "ps_scalars_upload: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->staging.ensure(32 * n + 32);
+    if (rc) return rc;
+    // staging is reused: make sure earlier consumers on the stream are done with it
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(c->staging.p, be32, 32 * n, hipMemcpyHostToDevice, c->stream));
+    rc = ps_scalars_from_device_be32(c, c->staging.p, n, out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // caller's buffer is not retained past return
+    return PS_OK;
+}
+
+extern "C" int ps_scalars_upload_i64(ps_ctx* c, const int64_t* v, size_t n, ps_scalars** out) {
+    if (!c || !out || (n && !v)) return fail(PS_ERR_ARG, "ps_scalars_upload_i64: NULL argument");
+    if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->staging.ensure(8 * n + 32);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(c->staging.p, v, 8 * n, hipMemcpyHostToDevice, c->stream));
+    rc = scalars_alloc(c, n, out);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_scalars_from_i64, dim3(nblocks(n)), dim3(256), 0, c->stream, (const int64_t*)c->staging.p,
+                              (u32)n, (u32*)(*out)->st->p);
+    HIP_TRY(hipGetLastError());
+    bool any_neg = false;
+    for (size_t i = 0; i < n; i++) any_neg |= v[i] < 0;
+    (*out)->max_bits = any_neg ? 255 : 64;  // non-negative witnesses need only ceil(64/c) windows
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PS_OK;
+}
+
+extern "C" int ps_scalars_download(ps_ctx* c, const ps_scalars* s, size_t first, size_t n, uint8_t* out) {
+    if (!c || !s || (n && !out)) return fail(PS_ERR_ARG, "ps_scalars_download: NULL argument");
+    if (first + n > s->n) return fail(PS_ERR_LENGTH, "ps_scalars_download: range out of bounds");
+    if (!n) return PS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = c->staging.ensure(32 * n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_scalars_to_be32, dim3(nblocks(n)), dim3(256), 0, c->stream, scalars_ptr(s) + 8 * first, (u32)n,
+                       (uint8_t*)c->staging.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->staging.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PS_OK;
+}
+extern "C" size_t ps_scalars_len(const ps_scalars* s) { return s ? s->n : 0; }
+extern "C" int ps_scalars_slice(const ps_scalars* s, size_t first, size_t n, ps_scalars** out) {
+    if (!s || !out) return fail(PS_ERR_ARG, "ps_scalars_slice: NULL argument");
+    if (first + n > s->n) return fail(PS_ERR_LENGTH, "ps_scalars_slice: range out of bounds");
+    s->st->refs++;
+    *out = new ps_scalars{n, s->st, s->first + first, s->max_bits, s->device};
+    return PS_OK;
+}
+extern "C" void ps_scalars_free(ps_scalars* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    storage_unref(s->st);
+    delete s;
+}
+
+// internal: wrap a fresh device allocation of n Fr values (plain limbs) produced by the library
+static ps_scalars* scalars_adopt(ps_ctx* c, void* dptr, size_t n) {
+    Storage* st = new Storage();
+    st->p = dptr;
+    return new ps_scalars{n, st, 0, 255, c->device};
+}
+
+// ---------------------------------------------------------------------------------------
+// points
+// ---------------------------------------------------------------------------------------
+static int points_alloc(ps_ctx* c, int group, size_t n, ps_points** out) {
+    Storage* st = new Storage();
+    hipError_t e = hipMalloc(&st->p, std::max<size_t>(point_bytes(group) * n, 256));
+    if (e != hipSuccess) {
+        delete st;
+        return fail(PS_ERR_HIP, std::string("hipMalloc points: ") + hipGetErrorString(e));
+    }
+    *out = new ps_points{group, n, st, 0, c->device};
+    return PS_OK;
+}
+
+extern "C" int ps_points_upload(ps_ctx* c, int group, const uint8_t* pts, size_t n, int fmt, ps_points** out) {
+    if (!c || !out || (n && !pts)) return fail(PS_ERR_ARG, "ps_points_upload: NULL argument");
+    if (group != PS_G1 && group != PS_G2) return fail(PS_ERR_ARG, "ps_points_upload: bad group");
+    if (fmt != PS_FMT_AFFINE) return fail(PS_ERR_ARG, "ps_points_upload: only PS_FMT_AFFINE is implemented");
+    if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t wb = wire_bytes(group);
+    int rc = c->staging.ensure(wb * n + 32);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(c->staging.p, pts, wb * n, hipMemcpyHostToDevice, c->stream));
+    rc = points_alloc(c, group, n, out);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+    if (n) {
+        if (group == PS_G1)
+            hipLaunchKernelGGL(k_points_from_bytes_g1, dim3(nblocks(n)), dim3(256), 0, c->stream,
+                               (const uint8_t*)c->staging.p, (u32)n, (Affine<Fp>*)(*out)->st->p, c->d_flag);
+        else
+            hipLaunchKernelGGL(k_points_from_bytes_g2, dim3(nblocks(n)), dim3(256), 0, c->stream,
+                               (const uint8_t*)c->staging.p, (u32)n, (Affine<Fp2>*)(*out)->st->p, c->d_flag);
+    }
+    HIP_TRY(hipGetLastError());
+    u32 nbad = 0;
+    HIP_TRY(hipMemcpyAsync(&nbad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (nbad) {
+        ps_points_free(*out);
+        *out = nullptr;
+        return fail(PS_ERR_ENCODING, std::to_string(nbad) + " point(s) not canonical / not on the curve");
+    }
+    return PS_OK;
+}
+
+template <class F>
+static int fixed_base(ps_ctx* c, int gi, const ps_scalars* k, ps_points* out) {
+    if (!c->fb_ready[gi]) {
+        int rc = c->fb_table[gi].ensure(sizeof(Affine<F>) * 32 * 256);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_fixed_base_table<F>, dim3(32), dim3(256), 0, c->stream, (Affine<F>*)c->fb_table[gi].p);
+        HIP_TRY(hipGetLastError());
+        c->fb_ready[gi] = true;
+    }
+    if (k->n)
+        hipLaunchKernelGGL(k_fixed_base_mul<F>, dim3(nblocks(k->n)), dim3(256), 0, c->stream,
+                           (const Affine<F>*)c->fb_table[gi].p, scalars_ptr(k), (u32)k->n, (Affine<F>*)out->st->p);
+    HIP_TRY(hipGetLastError());
+    return PS_OK;
+}
+
+extern "C" int ps_points_from_scalars(ps_ctx* c, int group, const ps_scalars* k, ps_points** out) {
+    if (!c || !k || !out) return fail(PS_ERR_ARG, "ps_points_from_scalars: NULL argument");
+    if (group != PS_G1 && group != PS_G2) return fail(PS_ERR_ARG, "bad group");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = points_alloc(c, group, k->n, out);
+    if (rc) return rc;
+    rc = group == PS_G1 ? fixed_base<Fp>(c, 0, k, *out) : fixed_base<Fp2>(c, 1, k, *out);
+    if (rc) {
+        ps_points_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" int ps_points_download(ps_ctx* c, const ps_points* p, size_t first, size_t n, uint8_t* out) {
+    if (!c || !p || (n && !out)) return fail(PS_ERR_ARG, "ps_points_download: NULL argument");
+    if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_download: range out of bounds");
+    if (!n) return PS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t wb = wire_bytes(p->group);
+    int rc = c->staging.ensure(wb * n);
+    if (rc) return rc;
+    const char* src = (const char*)points_ptr(p) + first * point_bytes(p->group);
+    if (p->group == PS_G1)
+        hipLaunchKernelGGL(k_points_to_bytes_g1, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<Fp>*)src, (u32)n,
+                           (uint8_t*)c->staging.p);
+    else
+        hipLaunchKernelGGL(k_points_to_bytes_g2, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<Fp2>*)src, (u32)n,
+                           (uint8_t*)c->staging.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->staging.p, wb * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PS_OK;
+}
+extern "C" size_t ps_points_len(const ps_points* p) { return p ? p->n : 0; }
+extern "C" int ps_points_group(const ps_points* p) { return p ? p->group : 0; }
+extern "C" int ps_points_slice(const ps_points* p, size_t first, size_t n, ps_points** out) {
+    if (!p || !out) return fail(PS_ERR_ARG, "ps_points_slice: NULL argument");
+    if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_slice: range out of bounds");
+    p->st->refs++;
+    *out = new ps_points{p->group, n, p->st, p->first + first, p->device};
+    return PS_OK;
+}
+extern "C" void ps_points_free(ps_points* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    storage_unref(p->st);
+    delete p;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side folding of window sums / partial sums (same field code, compiled for the host)
+// ---------------------------------------------------------------------------------------
+static void fp_to_be48_host(uint8_t* p, const Fp& a) {
+    Fp v = fe_from_mont<FpParams>(a);
+    limbs_to_be<12>(p, v.l);
+}
+static bool fp_from_be48_host(Fp& out, const uint8_t* p) {
+    Fp a;
+    limbs_from_be<12>(a.l, p);
+    if (!fe_is_canonical<FpParams>(a.l)) return false;
+    out = fe_to_mont<FpParams>(a);
+    return true;
+}
+static void write_affine(uint8_t* out, const Xyzz<Fp>& acc) {
+    Fp x, y;
+    if (!xyzz_to_affine<Fp>(acc, x, y)) {
+        memset(out, 0, 96);
+        out[0] = 0x40;
+        return;
+    }
+    fp_to_be48_host(out, x);
+    fp_to_be48_host(out + 48, y);
+}
+static void write_affine(uint8_t* out, const Xyzz<Fp2>& acc) {
+    Fp2 x, y;
+    if (!xyzz_to_affine<Fp2>(acc, x, y)) {
+        memset(out, 0, 192);
+        out[0] = 0x40;
+        return;
+    }
+    fp_to_be48_host(out, x.c1);
+    fp_to_be48_host(out + 48, x.c0);
+    fp_to_be48_host(out + 96, y.c1);
+    fp_to_be48_host(out + 144, y.c0);
+}
+static bool read_affine(Affine<Fp>& a, const uint8_t* p) {
+    if (p[0] & 0x40) { a.x = fe_zero<FpParams>(); a.y = fe_zero<FpParams>(); return true; }
+    if (p[0] & 0xE0) return false;
+    if (!fp_from_be48_host(a.x, p) || !fp_from_be48_host(a.y, p + 48)) return false;
+    return affine_on_curve<Fp>(a);
+}
+static bool read_affine(Affine<Fp2>& a, const uint8_t* p) {
+    if (p[0] & 0x40) { a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0); return true; }
+    if (p[0] & 0xE0) return false;
+    if (!fp_from_be48_host(a.x.c1, p) || !fp_from_be48_host(a.x.c0, p + 48) || !fp_from_be48_host(a.y.c1, p + 96) ||
+        !fp_from_be48_host(a.y.c0, p + 144))
+        return false;
+    return affine_on_curve<Fp2>(a);
+}
+
+template <class F>
+static int points_sum_t(const uint8_t* pts, size_t k, uint8_t* out, size_t wb) {
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (size_t i = 0; i < k; i++) {
+        Affine<F> a;
+        if (!read_affine(a, pts + wb * i)) return fail(PS_ERR_ENCODING, "ps_points_sum: bad point encoding");
+        if (!affine_is_identity<F>(a)) xyzz_madd<F>(acc, a.x, a.y);
+    }
+    write_affine(out, acc);
+    return PS_OK;
+}
+extern "C" int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* out) {
+    if ((k && !pts) || !out) return fail(PS_ERR_ARG, "ps_points_sum: NULL argument");
+    if (group == PS_G1) return points_sum_t<Fp>(pts, k, out, 96);
+    if (group == PS_G2) return points_sum_t<Fp2>(pts, k, out, 192);
+    return fail(PS_ERR_ARG, "bad group");
+}
+
+// ---------------------------------------------------------------------------------------
+// MSM driver
+// ---------------------------------------------------------------------------------------
+template <class F>
+static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl) {
+    const size_t n = sc->n;
+    const u64 total = (u64)pl.W * n;  // upper bound on entries
+    const u64 G = pl.G;
+    const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
+    const u32 segs_per_win = pl.NB / (u32)pl.SEG;
+    const u32 nseg_total = segs_per_win * (u32)pl.W;
+    const u32 scan_tiles = (u32)((G + SCAN_TILE - 1) / SCAN_TILE);
+    int rc;
+    if ((rc = c->counts.ensure(4 * G))) return rc;
+    if ((rc = c->offs.ensure(4 * (G + 1)))) return rc;
+    if ((rc = c->bsum.ensure(4 * (size_t)scan_tiles + 4))) return rc;
+    if ((rc = c->keys.ensure(4 * total))) return rc;
+    if ((rc = c->ranks.ensure(4 * total))) return rc;
+    if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
+    if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
+    if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
+    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (size_t)nseg_total))) return rc;
+    if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
+    if (sizeof(Xyzz<F>) * (size_t)pl.W + 64 > c->h_pinned_cap) return fail(PS_ERR_ARG, "too many windows");
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
+    HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
+    hipLaunchKernelGGL(k_digits, dim3(nblocks(n)), dim3(256), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB,
+                       (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->ranks.p);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
+                       (u32*)c->bsum.p, (u64)G);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
+    hipLaunchKernelGGL(k_scan_add, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (u32*)c->offs.p, (const u32*)c->bsum.p, (u64)G);
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->ranks.p,
+                       (const u32*)c->offs.p, (u32)n, total, (u32*)c->sorted.p);
+    hipLaunchKernelGGL(k_accumulate<F>, dim3(nblocks(nthreads_acc)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
+                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,
+                       (Xyzz<F>*)c->parts.p);
+    hipLaunchKernelGGL(k_fixup<F>, dim3(nblocks(G)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
+                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p);
+    hipLaunchKernelGGL(k_reduce_segments<F>, dim3(nblocks(nseg_total)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
+                       pl.NB, pl.SEG, nseg_total, (Xyzz<F>*)c->segs.p);
+    hipLaunchKernelGGL(k_reduce_windows<F>, dim3(pl.W), dim3(256), 256 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)c->segs.p,
+                       segs_per_win, (Xyzz<F>*)c->wins.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->wins.p, sizeof(Xyzz<F>) * pl.W, hipMemcpyDeviceToHost, st));
+    // entry count for introspection (read back with the window sums)
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + c->h_pinned_cap - 8, (u32*)c->offs.p + G, 4, hipMemcpyDeviceToHost, st));
+    return PS_OK;
+}
+
+template <class F>
+static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, uint8_t* out) {
+    const Xyzz<F>* wins = (const Xyzz<F>*)c->h_pinned;
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (int w = pl.W - 1; w >= 0; w--) {
+        for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
+        xyzz_add<F>(acc, wins[w]);
+    }
+    write_affine(out, acc);
+}
+
+extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* sc) {
+    if (!c || !pts || !sc) return fail(PS_ERR_ARG, "ps_msm: NULL argument");
+    if (pts->n != sc->n)  // algebra.go:350-352
+        return fail(PS_ERR_LENGTH, "mismatch of length between poly " + std::to_string(sc->n) + " and blinded eval points " +
+                                       std::to_string(pts->n));
+    if (c->pending) return fail(PS_ERR_ARG, "ps_msm_launch: an MSM is already pending on this context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (sc->n == 0) {
+        c->pending = true;
+        c->pending_group = pts->group;
+        c->pending_plan = MsmPlan{};
+        return PS_OK;
+    }
+    MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
+    int rc = pts->group == PS_G1 ? msm_launch_t<Fp>(c, pts, sc, pl) : msm_launch_t<Fp2>(c, pts, sc, pl);
+    if (rc) return rc;
+    c->pending = true;
+    c->pending_group = pts->group;
+    c->pending_plan = pl;
+    return PS_OK;
+}
+
+extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
+    if (!c || !out) return fail(PS_ERR_ARG, "ps_msm_finish: NULL argument");
+    if (!c->pending) return fail(PS_ERR_ARG, "ps_msm_finish: nothing pending");
+    c->pending = false;
+    const MsmPlan& pl = c->pending_plan;
+    if (pl.W == 0) {  // empty sum: the identity (zero.Clone(), algebra.go:353)
+        memset(out, 0, wire_bytes(c->pending_group));
+        out[0] = 0x40;
+        return PS_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->pending_group == PS_G1) msm_fold_host<Fp>(c, pl, out);
+    else msm_fold_host<Fp2>(c, pl, out);
+    u32 entries = *(u32*)((char*)c->h_pinned + c->h_pinned_cap - 8);
+    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    return PS_OK;
+}
+
+extern "C" int ps_msm(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, uint8_t* out) {
+    int rc = ps_msm_launch(c, pts, sc);
+    if (rc) return rc;
+    return ps_msm_finish(c, out);
+}
+extern "C" int ps_msm_be32(ps_ctx* c, const ps_points* pts, const uint8_t* be32, size_t n, uint8_t* out) {
+    ps_scalars* s = nullptr;
+    int rc = ps_scalars_upload(c, be32, n, &s);
+    if (rc) return rc;
+    rc = ps_msm(c, pts, s, out);
+    ps_scalars_free(s);
+    return rc;
+}
+extern "C" int ps_msm_i64(ps_ctx* c, const ps_points* pts, const int64_t* v, size_t n, uint8_t* out) {
+    ps_scalars* s = nullptr;
+    int rc = ps_scalars_upload_i64(c, v, n, &s);
+    if (rc) return rc;
+    rc = ps_msm(c, pts, s, out);
+    ps_scalars_free(s);
+    return rc;
+}
+extern "C" int ps_msm_last_info(ps_ctx* c, ps_msm_info* out) {
+    if (!c || !out) return fail(PS_ERR_ARG, "NULL argument");
+    *out = c->last_info;
+    return PS_OK;
+}
+extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {
+    if (!c || bits < 0 || bits > 20 || (bits > 0 && bits < 4)) return fail(PS_ERR_ARG, "window bits must be 0 or 4..20");
+    c->forced_c = bits;
+    return PS_OK;
+}
+
+#include "prove.inc"

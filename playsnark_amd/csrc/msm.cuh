@@ -1,0 +1,505 @@
+// Pippenger bucket MSM for BLS12-381 G1 / G2 on gfx950 -- the replacement for the reference's
+// serial "blind evaluation" loop  acc = acc.Add(acc, tmp.Mul(p[i], blindedPoint[i]))
+// (algebra.go:355-357; also groth16.go:176-178, pinochio.go:225-227).
+//
+// Pipeline (all on one HIP stream, no host round trip until the W window sums come back):
+//   1 k_digits      signed c-bit digits per scalar; a returning global atomic on the bucket
+//                   counter gives each (scalar, window) its rank inside its bucket
+//   2 k_scan_*      exclusive prefix sum of the W*2^(c-1) bucket counters (wave shuffles + LDS)
+//   3 k_scatter     counting-sort scatter: sorted[offs[bucket] + rank] = point index | sign
+//   4 k_accumulate  the hot kernel.  Each thread owns a fixed slice of M consecutive sorted
+//                   entries -- perfectly balanced whatever the bucket-size distribution (skewed
+//                   witness vectors, repeated scalars) -- and walks it with an XYZZ accumulator,
+//                   flushing whenever the bucket id changes.  Buckets that lie inside one slice
+//                   are final; runs cut by a slice boundary go to a head/tail partial slot.
+//   5 k_fixup       per bucket: add up the partial slots of the slices it spans
+//   6 k_reduce_*    per window  sum_b (b+1)*B[b]  by segment running sums + LDS tree
+//   host            Horner over the W window sums (c doublings each) and affine normalisation
+//
+// Data layout in HBM: points AoS affine Montgomery (96 B G1 / 192 B G2, 16-B aligned, read with
+// dwordx4 loads); scalars 8 x u32 little-endian plain; keys/ranks/sorted as [W][n] u32 so the
+// digit kernel's stores are coalesced across scalars; buckets and partials AoS XYZZ.
+#pragma once
+#include "curve.cuh"
+
+namespace ps {
+
+struct MsmPlan {
+    int c;       // window bits
+    int W;       // windows
+    u32 NB;      // buckets per window = 2^(c-1)
+    u64 G;       // W * NB
+    int M;       // sorted entries per accumulation thread
+    int SEG;     // buckets per reduction thread
+};
+
+// cost model in field multiplications: N*W mixed adds (10) + G * (fix-up + 2 reduction adds) (42)
+static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
+    MsmPlan best{};
+    double best_cost = 1e300;
+    for (int c = 4; c <= 20; c++) {  // c >= 4 keeps W <= 64
+        if (forced_c && c != forced_c) continue;
+        int W = max_bits / c + 1;
+        double nb = (double)(1u << (c - 1));
+        double cost = (double)n * W * 10.0 + W * nb * 42.0;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best.c = c;
+            best.W = W;
+        }
+    }
+    best.NB = 1u << (best.c - 1);
+    best.G = (u64)best.W * best.NB;
+    best.M = 32;
+    best.SEG = best.NB >= 32 ? 32 : (int)best.NB;
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------
+// 1. digits
+// ---------------------------------------------------------------------------------------
+PS_INL u32 limb_sel8(const u32* k, int i) {  // k[i] without dynamic register indexing
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v = (i == j) ? k[j] : v;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
+                                                u32* __restrict__ counts, u32* __restrict__ keys,
+                                                u32* __restrict__ ranks) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 k[8];
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
+    uint4 a = sp[0], b = sp[1];
+    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+    const u32 mask = (1u << c) - 1u;
+    u32 carry = 0;
+    for (int w = 0; w < W; w++) {
+        int bit = w * c;
+        int li = bit >> 5, sh = bit & 31;
+        u64 two = (u64)limb_sel8(k, li) | ((u64)limb_sel8(k, li + 1) << 32);
+        u32 d = ((u32)(two >> sh) & mask) + carry;
+        u32 neg = d > NB ? 1u : 0u;
+        carry = neg;
+        if (neg) d = (1u << c) - d;
+        u32 key = 0xffffffffu, rank = 0;
+        if (d) {
+            key = (u32)w * NB + d - 1u;
+            rank = atomicAdd(&counts[key], 1u) | (neg << 31);
+        }
+        keys[(size_t)w * n + i] = key;
+        ranks[(size_t)w * n + i] = rank;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. exclusive scan of u32 counters (2048 items per 256-thread block)
+// ---------------------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+__device__ inline u32 wave_incl_scan(u32 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, total in *total
+__device__ inline u32 block_excl_scan(u32 v, u32* total) {
+    __shared__ u32 wsum[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    u32 inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) {
+        u32 s = wsum[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_blocks(const u32* __restrict__ in, u32* __restrict__ out,
+                                                            u32* __restrict__ bsum, u64 n) {
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 v[SCAN_ITEMS];
+    u32 s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        v[j] = (base + j < n) ? in[base + j] : 0u;
+        s += v[j];
+    }
+    u32 total;
+    u32 ex = block_excl_scan(s, &total);
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the per-tile sums in place; grand total appended at out_total
+__global__ void __launch_bounds__(1024) k_scan_top(u32* __restrict__ bsum, u32 nb, u32* __restrict__ out_total) {
+    __shared__ u32 carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 start = 0; start < nb; start += 1024) {
+        u32 idx = start + threadIdx.x;
+        u32 v = idx < nb ? bsum[idx] : 0u;
+        u32 total;
+        u32 ex = block_excl_scan(v, &total);
+        u32 carry = carry_s;
+        if (idx < nb) bsum[idx] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_total = carry_s;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(u32* __restrict__ out, const u32* __restrict__ bsum, u64 n) {
+    u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+    u32 add = bsum[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++)
+        if (base + j < n) out[base + j] += add;
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. scatter
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ keys, const u32* __restrict__ ranks,
+                                                 const u32* __restrict__ offs, u32 n, u64 total,
+                                                 u32* __restrict__ sorted) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    u32 key = keys[idx];
+    if (key == 0xffffffffu) return;
+    u32 r = ranks[idx];
+    u32 pos = offs[key] + (r & 0x7fffffffu);
+    sorted[pos] = (u32)(idx % n) | (r & 0x80000000u);
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. bucket accumulation over fixed slices of the sorted entry list
+// ---------------------------------------------------------------------------------------
+template <class F>
+PS_INL bool affine_is_identity(const Affine<F>& p) { return f_is_zero(p.x) & f_is_zero(p.y); }
+
+template <class F>
+__device__ inline void flush_run(const Xyzz<F>& acc, u32 g, u32 rs, u32 re, u32 slice_start, u32 t,
+                                 const u32* __restrict__ offs, Xyzz<F>* __restrict__ buckets,
+                                 Xyzz<F>* __restrict__ parts) {
+    bool whole = (rs == offs[g]) && (re == offs[g + 1]);
+    if (whole) buckets[g] = acc;
+    else if (rs == slice_start) parts[2 * (size_t)t] = acc;
+    else parts[2 * (size_t)t + 1] = acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<F>* __restrict__ points,
+                                                       const u32* __restrict__ sorted, const u32* __restrict__ offs,
+                                                       u32 G, int M, Xyzz<F>* __restrict__ buckets,
+                                                       Xyzz<F>* __restrict__ parts) {
+    const u32 E = offs[G];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 start64 = (u64)t * (u64)M;
+    if (start64 >= E) return;
+    const u32 start = (u32)start64;
+    const u32 end = (E - start < (u32)M) ? E : start + (u32)M;
+    // bucket containing `start`: largest g with offs[g] <= start (and offs[g+1] > start)
+    u32 lo = 0, hi = G;  // invariant: offs[lo] <= start < offs[hi]
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (offs[mid] <= start) lo = mid; else hi = mid;
+    }
+    u32 g = lo;
+    u32 bend = offs[g + 1];
+    u32 run_start = start;
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (u32 p = start; p < end; p++) {
+        if (p >= bend) {
+            flush_run<F>(acc, g, run_start, p, start, t, offs, buckets, parts);
+            acc = xyzz_identity<F>();
+            run_start = p;
+            do { g++; bend = offs[g + 1]; } while (bend <= p);
+        }
+        u32 e = sorted[p];
+        Affine<F> pt = points[e & 0x7fffffffu];
+        if (!affine_is_identity<F>(pt)) {
+            if (e >> 31) pt.y = f_neg(pt.y);
+            xyzz_madd<F>(acc, pt.x, pt.y);
+        }
+    }
+    flush_run<F>(acc, g, run_start, end, start, t, offs, buckets, parts);
+}
+
+// ---------------------------------------------------------------------------------------
+// 5. fix-up of buckets cut by slice boundaries
+// ---------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, u32 G, int M,
+                                                  const Xyzz<F>* __restrict__ parts, Xyzz<F>* __restrict__ buckets) {
+    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    u32 lo = offs[g], hi = offs[g + 1];
+    if (lo == hi) return;  // empty bucket: stays the identity from the memset
+    u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
+    if (t0 == t1) return;  // lay inside one slice: already final
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (u32 t = t0; t <= t1; t++) {
+        u32 slice_start = t * (u32)M;
+        u32 rs = lo > slice_start ? lo : slice_start;
+        Xyzz<F> part = parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)];
+        xyzz_add<F>(acc, part);
+    }
+    buckets[g] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// 6. bucket reduction: window sum = sum_{b=0}^{NB-1} (b+1) * B[b]
+// ---------------------------------------------------------------------------------------
+// stage 1: thread (w, s) owns buckets [s*SEG, (s+1)*SEG): running sum from the top,
+//          seg = sum (b - s*SEG + 1) B[b] + (s*SEG) * sum B[b]
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_reduce_segments(const Xyzz<F>* __restrict__ buckets, u32 NB, int SEG,
+                                                            u32 nseg_total, Xyzz<F>* __restrict__ segs) {
+    u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nseg_total) return;
+    u32 segs_per_win = NB / (u32)SEG;
+    u32 w = idx / segs_per_win, s = idx % segs_per_win;
+    const Xyzz<F>* B = buckets + (size_t)w * NB + (size_t)s * SEG;
+    Xyzz<F> run = xyzz_identity<F>(), acc = xyzz_identity<F>();
+    for (int b = SEG - 1; b >= 0; b--) {
+        Xyzz<F> v = B[b];
+        xyzz_add<F>(run, v);
+        xyzz_add<F>(acc, run);
+    }
+    u32 off = s * (u32)SEG;
+    if (off) {
+        Xyzz<F> sh = xyzz_mul_small<F>(run, off);
+        xyzz_add<F>(acc, sh);
+    }
+    segs[idx] = acc;
+}
+
+// stage 2: one block per window sums its segment values (serial stride + LDS tree)
+template <class F>
+__global__ void __launch_bounds__(256) k_reduce_windows(const Xyzz<F>* __restrict__ segs, u32 segs_per_win,
+                                                        Xyzz<F>* __restrict__ win_sums) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Xyzz<F>* sm = reinterpret_cast<Xyzz<F>*>(smem_raw);
+    const u32 w = blockIdx.x;
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (u32 s = threadIdx.x; s < segs_per_win; s += blockDim.x) {
+        Xyzz<F> v = segs[(size_t)w * segs_per_win + s];
+        xyzz_add<F>(acc, v);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) {
+            Xyzz<F> a = sm[threadIdx.x], b = sm[threadIdx.x + stride];
+            xyzz_add<F>(a, b);
+            sm[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) win_sums[w] = sm[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// auxiliary kernels: format conversion, fixed-base multiplication
+// ---------------------------------------------------------------------------------------
+// big-endian canonical bytes -> plain little-endian limbs, reduced mod r (scalars)
+__global__ void __launch_bounds__(256) k_scalars_from_be32(const uint8_t* __restrict__ in, u32 n, u32* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32* src = reinterpret_cast<const u32*>(in) + 8 * (size_t)i;
+    u32 k[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) k[j] = __builtin_bswap32(src[7 - j]);
+    // reduce: 2^256 / r < 2.3 so at most two subtractions
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) fe_reduce_once<FrParams>(k, 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[8 * (size_t)i + j] = k[j];
+}
+
+__global__ void __launch_bounds__(256) k_scalars_to_be32(const u32* __restrict__ in, u32 n, uint8_t* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32* dst = reinterpret_cast<u32*>(out) + 8 * (size_t)i;
+#pragma unroll
+    for (int j = 0; j < 8; j++) dst[7 - j] = __builtin_bswap32(in[8 * (size_t)i + j]);
+}
+
+// SetInt64 (curve.go:17-19)
+__global__ void __launch_bounds__(256) k_scalars_from_i64(const int64_t* __restrict__ in, u32 n, u32* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t v = in[i];
+    u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+    Fr a = fe_zero<FrParams>();
+    a.l[0] = (u32)mag;
+    a.l[1] = (u32)(mag >> 32);
+    if (v < 0) a = fe_neg<FrParams>(a);
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[8 * (size_t)i + j] = a.l[j];
+}
+
+// raw big-endian coordinate (48 B) -> Montgomery Fp; ok=false if not canonical
+__device__ inline Fp fp_from_be48(const uint8_t* p, bool& ok) {
+    const u32* src = reinterpret_cast<const u32*>(p);
+    Fp a;
+#pragma unroll
+    for (int j = 0; j < 12; j++) a.l[j] = __builtin_bswap32(src[11 - j]);
+    ok = ok && fe_is_canonical<FpParams>(a.l);
+    return fe_to_mont<FpParams>(a);
+}
+__device__ inline void fp_to_be48(uint8_t* p, const Fp& a) {
+    Fp v = fe_from_mont<FpParams>(a);
+    u32* dst = reinterpret_cast<u32*>(p);
+#pragma unroll
+    for (int j = 0; j < 12; j++) dst[11 - j] = __builtin_bswap32(v.l[j]);
+}
+
+PS_INL Fp curve_b(const Fp*) { Fp b; constexpr u32 v[12] = PS_FP_FOUR;
+#pragma unroll
+    for (int i = 0; i < 12; i++) b.l[i] = v[i];
+    return b; }
+PS_INL Fp2 curve_b(const Fp2*) { Fp b = curve_b((const Fp*)0); return Fp2{b, b}; }
+
+template <class F>
+PS_HD inline bool affine_on_curve(const Affine<F>& p) {
+    F lhs = f_sqr(p.y);
+    F rhs = f_add(f_mul(f_sqr(p.x), p.x), curve_b((const F*)0));
+    return f_eq(lhs, rhs);
+}
+
+// ZCash uncompressed bytes -> device layout; bad points counted in *nbad
+__global__ void __launch_bounds__(256) k_points_from_bytes_g1(const uint8_t* __restrict__ in, u32 n,
+                                                              Affine<Fp>* __restrict__ out, u32* __restrict__ nbad) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = in + 96 * (size_t)i;
+    Affine<Fp> a;
+    if (p[0] & 0x40) {
+        a.x = fe_zero<FpParams>(); a.y = fe_zero<FpParams>();
+    } else {
+        bool ok = (p[0] & 0xE0) == 0;
+        a.x = fp_from_be48(p, ok);
+        a.y = fp_from_be48(p + 48, ok);
+        ok = ok && affine_on_curve<Fp>(a);
+        if (!ok) atomicAdd(nbad, 1u);
+    }
+    out[i] = a;
+}
+__global__ void __launch_bounds__(256) k_points_from_bytes_g2(const uint8_t* __restrict__ in, u32 n,
+                                                              Affine<Fp2>* __restrict__ out, u32* __restrict__ nbad) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = in + 192 * (size_t)i;
+    Affine<Fp2> a;
+    if (p[0] & 0x40) {
+        a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0);
+    } else {
+        bool ok = (p[0] & 0xE0) == 0;
+        a.x.c1 = fp_from_be48(p, ok);
+        a.x.c0 = fp_from_be48(p + 48, ok);
+        a.y.c1 = fp_from_be48(p + 96, ok);
+        a.y.c0 = fp_from_be48(p + 144, ok);
+        ok = ok && affine_on_curve<Fp2>(a);
+        if (!ok) atomicAdd(nbad, 1u);
+    }
+    out[i] = a;
+}
+__global__ void __launch_bounds__(256) k_points_to_bytes_g1(const Affine<Fp>* __restrict__ in, u32 n,
+                                                            uint8_t* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* p = out + 96 * (size_t)i;
+    Affine<Fp> a = in[i];
+    fp_to_be48(p, a.x);
+    fp_to_be48(p + 48, a.y);
+    if (affine_is_identity<Fp>(a)) p[0] = 0x40;
+}
+__global__ void __launch_bounds__(256) k_points_to_bytes_g2(const Affine<Fp2>* __restrict__ in, u32 n,
+                                                            uint8_t* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* p = out + 192 * (size_t)i;
+    Affine<Fp2> a = in[i];
+    fp_to_be48(p, a.x.c1);
+    fp_to_be48(p + 48, a.x.c0);
+    fp_to_be48(p + 96, a.y.c1);
+    fp_to_be48(p + 144, a.y.c0);
+    if (affine_is_identity<Fp2>(a)) p[0] = 0x40;
+}
+
+PS_INL Affine<Fp> generator(const Fp*) {
+    Affine<Fp> g;
+    constexpr u32 x[12] = PS_G1_GEN_X; constexpr u32 y[12] = PS_G1_GEN_Y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { g.x.l[i] = x[i]; g.y.l[i] = y[i]; }
+    return g;
+}
+PS_INL Affine<Fp2> generator(const Fp2*) {
+    Affine<Fp2> g;
+    constexpr u32 x0[12] = PS_G2_GEN_X0; constexpr u32 x1[12] = PS_G2_GEN_X1;
+    constexpr u32 y0[12] = PS_G2_GEN_Y0; constexpr u32 y1[12] = PS_G2_GEN_Y1;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { g.x.c0.l[i] = x0[i]; g.x.c1.l[i] = x1[i]; g.y.c0.l[i] = y0[i]; g.y.c1.l[i] = y1[i]; }
+    return g;
+}
+
+// Fixed-base table: T[j][d] = d * 2^(8j) * G for j = 0..31, d = 0..255 (d = 0 unused).
+// out[i] = sum_j T[j][byte_j(k_i)]: 32 mixed additions per scalar instead of 255 doublings +
+// ~128 additions.  This is the device form of Point.Mul(s, nil) (curve.go:25-31, algebra.go:373).
+template <class F>
+__global__ void __launch_bounds__(256) k_fixed_base_table(Affine<F>* __restrict__ table) {
+    // one thread per (j, d); d*2^(8j)*G by double-and-add on the generator
+    u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 32 * 256) return;
+    u32 j = idx >> 8, d = idx & 255;
+    Affine<F> g = generator((const F*)0);
+    Xyzz<F> base = xyzz_from_affine<F>(g.x, g.y);
+    for (u32 i = 0; i < 8 * j; i++) base = xyzz_dbl<F>(base);
+    Xyzz<F> acc = xyzz_mul_small<F>(base, d);
+    Affine<F> out;
+    if (!xyzz_to_affine<F>(acc, out.x, out.y)) { out.x = f_zero((const F*)0); out.y = f_zero((const F*)0); }
+    table[idx] = out;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const Affine<F>* __restrict__ table,
+                                                           const u32* __restrict__ scalars, u32 n,
+                                                           Affine<F>* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (int j = 0; j < 32; j++) {
+        u32 limb = scalars[8 * (size_t)i + (j >> 2)];
+        u32 d = (limb >> (8 * (j & 3))) & 255u;
+        if (d) {
+            Affine<F> t = table[j * 256 + d];
+            xyzz_madd<F>(acc, t.x, t.y);
+        }
+    }
+    Affine<F> r;
+    if (!xyzz_to_affine<F>(acc, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
+    out[i] = r;
+}
+
+}  // namespace ps

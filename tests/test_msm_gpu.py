@@ -1,0 +1,191 @@
+"""GPU parity: the HIP MSM (through the C ABI) against the oracle, bit-exact on the affine bytes.
+
+Reference behaviour under test: Poly.BlindEval (algebra.go:348-359), its int64-scalar twins
+(groth16.go:176-178, pinochio.go:222-229) and the length-mismatch panic (algebra.go:350-352).
+Method of the reference's own tests (algebra_test.go:21-35): compare against an independently
+computed group element.
+"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x706C6179736E61726B & 0xFFFFFFFFFFFFFFFF
+
+
+def _rng(pr, salt=0):
+    return pr.SplitMix64(SEED + salt)
+
+
+def _grp(ps_api, co, name):
+    return (ps_api.G1, co.G1) if name == "g1" else (ps_api.G2, co.G2)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_fixed_base_matches_oracle(ps_api, ctx, co, pr, name):
+    """Point.Mul(s, nil) = s*G (curve.go:25-31, algebra.go:373) on the device."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 1)
+    ks = [0, 1, 2, 3, 255, 256, pr.R - 1, pr.R - 2, 1 << 254] + [rng.fr() for _ in range(23)]
+    pts = ps_api.Points.from_scalars(ctx, gid, ps_api.Poly.upload(ctx, ks))
+    got = og.unpack(pts.download())
+    for k, g in zip(ks, got):
+        assert g == og.mul(k), hex(k)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_points_roundtrip_and_validation(ps_api, ctx, co, pr, name):
+    gid, og = _grp(ps_api, co, name)
+    raw = og.gen_points(12345, 6789, 9) + og.to_b(None)
+    pts = ps_api.Points.upload(ctx, gid, raw)
+    assert len(pts) == 10 and pts.download() == raw
+    assert pts.slice(3, 4).download() == raw[3 * og.nb : 7 * og.nb]
+    bad = bytearray(raw)
+    bad[og.nb - 1] ^= 1  # y of point 0 off the curve
+    with pytest.raises(ps_api.PlaysnarkError) as e:
+        ps_api.Points.upload(ctx, gid, bytes(bad))
+    assert e.value.code == -3
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 5, 64, 333, 1024])
+def test_blind_eval_small_vs_reference_loop(ps_api, ctx, co, pr, name, n):
+    """TestAlgebraBlindEval / TestPinocchioCombine shape: GPU MSM == serial Mul+Add loop."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 100 + n)
+    sc = [rng.fr() for _ in range(n)]
+    raw = og.gen_points(rng.fr(), rng.fr(), n)
+    got = ps_api.Poly.upload(ctx, sc).BlindEval(ps_api.Points.upload(ctx, gid, raw))
+    want = og.to_b(og.blind_eval(sc, raw)) if n <= 64 else og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+    assert got == want
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_blind_eval_edge_scalars_and_points(ps_api, ctx, co, pr, name):
+    """Zero / one / r-1 scalars, identity points, repeated points (forces the doubling branch
+    of the bucket adder) and P, -P pairs (forces the cancellation branch)."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 7)
+    base = og.unpack(og.gen_points(rng.fr(), rng.fr(), 6))
+    P, Q = base[0], base[1]
+    negP = (P[0], (pr.P - P[1]) % pr.P) if name == "g1" else (P[0], ((-P[1][0]) % pr.P, (-P[1][1]) % pr.P))
+    k = rng.fr()
+    cases = [
+        ([0, 0, 0], [P, Q, base[2]]),
+        ([1, 1, 1], [P, Q, base[2]]),
+        ([pr.R - 1, pr.R - 1], [P, Q]),
+        ([k, k, k, k, k], [P, P, P, P, P]),              # same bucket, same point: doubling
+        ([k, k], [P, negP]),                              # same bucket, opposite points: identity
+        ([k, pr.R - k], [P, P]),                          # k*P + (-k)*P = O
+        ([k, 5, 7], [None, P, None]),                     # identity inputs
+        ([3, 3, 3, 3, 3, 3], base),
+        ([(1 << 255) % pr.R, (1 << 128) - 1, 1 << 64], base[:3]),
+    ]
+    for sc, pts in cases:
+        raw = og.pack(pts)
+        got = ps_api.Poly.upload(ctx, sc).BlindEval(ps_api.Points.upload(ctx, gid, raw))
+        assert got == og.to_b(og.blind_eval(sc, raw)), (sc, name)
+
+
+def test_blind_eval_length_mismatch_is_the_reference_panic(ps_api, ctx, co):
+    raw = co.G1.gen_points(1, 1, 4)
+    pts = ps_api.Points.upload(ctx, ps_api.G1, raw)
+    with pytest.raises(ps_api.LengthMismatch) as e:
+        ps_api.Poly.upload(ctx, [1, 2, 3]).BlindEval(pts)
+    assert "mismatch of length between poly 3 and blinded eval points 4" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_blind_eval_int64_witness_scalars(ps_api, ctx, co, pr, name):
+    """computeSolCommit / NioLP loop: Value.ToFieldElement scalars incl. negatives, zeros, ones."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 9)
+    n = 200
+    vals = [0, 1, 1, 0, -1, 35, 9, 27, 30, -(1 << 62), (1 << 63) - 1] + [
+        int(rng.next() % 1000) - 100 for _ in range(n - 11)
+    ]
+    raw = og.gen_points(rng.fr(), rng.fr(), n)
+    pts = ps_api.Points.upload(ctx, gid, raw)
+    got = ps_api.Poly.from_values(ctx, vals).BlindEval(pts)
+    assert got == og.to_b(og.blind_eval_i64(vals, raw))
+    # all non-negative: the short-scalar plan (fewer windows) must give the same point
+    pos = [abs(v) for v in vals]
+    got = ps_api.Poly.from_values(ctx, pos).BlindEval(pts)
+    assert got == og.to_b(og.blind_eval_i64(pos, raw))
+    assert ctx.last_msm_info()["windows"] * ctx.last_msm_info()["window_bits"] < 128
+
+
+@pytest.mark.parametrize("c", [4, 5, 7, 11, 16])
+def test_window_size_does_not_change_the_result(ps_api, ctx, co, pr, c):
+    rng = _rng(pr, 11)
+    n = 777
+    sc = [rng.fr() for _ in range(n)]
+    raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
+    pts = ps_api.Points.upload(ctx, ps_api.G1, raw)
+    want = co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+    try:
+        ctx.set_window(c)
+        assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want
+        assert ctx.last_msm_info()["window_bits"] == c
+    finally:
+        ctx.set_window(0)
+
+
+def test_skewed_scalars_heavy_buckets(ps_api, ctx, co, pr):
+    """All-equal scalars put every point of a window into one bucket (SURVEY 8d regime iii):
+    exercises slices that lie wholly inside one bucket and the multi-slice fix-up."""
+    rng = _rng(pr, 13)
+    n = 5000
+    k = rng.fr()
+    raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
+    pts = ps_api.Points.upload(ctx, ps_api.G1, raw)
+    for sc in ([k] * n, [pr.R - 1] * n, [1] * (n // 2) + [0] * (n - n // 2)):
+        want = co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+        assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want
+
+
+def test_config2_g1_msm_2pow16_bit_exact(ps_api, ctx, co, pr):
+    """BASELINE config #2: synthetic 2^16-point BLS12-381 G1 MSM, bit-exact vs the CPU oracle."""
+    rng = _rng(pr, 16)
+    n = 1 << 16
+    sc = co.pack_fr([rng.fr() for _ in range(n)])
+    raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
+    want = co.G1.to_b(co.G1.msm_pippenger(sc, raw, n, 8))
+    got = ps_api.Poly.upload(ctx, sc).BlindEval(ps_api.Points.upload(ctx, ps_api.G1, raw))
+    assert got == want
+
+
+def test_g2_msm_2pow12_bit_exact(ps_api, ctx, co, pr):
+    rng = _rng(pr, 17)
+    n = 1 << 12
+    sc = co.pack_fr([rng.fr() for _ in range(n)])
+    raw = co.G2.gen_points(rng.fr(), rng.fr(), n)
+    want = co.G2.to_b(co.G2.msm_pippenger(sc, raw, n, 8))
+    got = ps_api.Poly.upload(ctx, sc).BlindEval(ps_api.Points.upload(ctx, ps_api.G2, raw))
+    assert got == want
+
+
+def test_dlog_identity_on_device_generated_points(ps_api, ctx, co, pr):
+    """The reference's own oracle method (groth16_test.go:41-50): with P_i = a_i*G,
+    sum k_i P_i == (sum k_i a_i)*G.  Points come from the device fixed-base kernel."""
+    rng = _rng(pr, 19)
+    n = 3000
+    a = [rng.fr() for _ in range(n)]
+    k = [rng.fr() for _ in range(n)]
+    pts = ps_api.Points.from_scalars(ctx, ps_api.G1, ps_api.Poly.upload(ctx, a))
+    got = ps_api.Poly.upload(ctx, k).BlindEval(pts)
+    dlog = sum(x * y for x, y in zip(a, k)) % pr.R
+    assert got == co.G1.to_b(co.G1.mul(dlog))
+
+
+def test_points_sum_folds_partial_sums(ps_api, co, pr):
+    rng = _rng(pr, 23)
+    raw = co.G1.gen_points(rng.fr(), rng.fr(), 8) + co.G1.to_b(None)
+    want = None
+    for p in co.G1.unpack(raw):
+        want = co.G1.add(want, p)
+    assert ps_api.points_sum(ps_api.G1, raw) == co.G1.to_b(want)
+    raw2 = co.G2.gen_points(rng.fr(), rng.fr(), 5)
+    want = None
+    for p in co.G2.unpack(raw2):
+        want = co.G2.add(want, p)
+    assert ps_api.points_sum(ps_api.G2, raw2) == co.G2.to_b(want)
