@@ -103,7 +103,13 @@ typedef struct {
     int slice;         /* sorted entries per accumulation thread */
 } ps_msm_info;
 int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
-int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic */);
+int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic, else 4..20 */);
+/* Per-stage device time of the last MSM, measured with HIP events on the context's own stream
+ * (the stream the kernels run on).  Stages: 0 digits (+counter/bucket memsets), 1 scan,
+ * 2 scatter, 3 accumulate (the dominant kernel), 4 fix-up, 5 bucket reduction. */
+#define PS_MSM_STAGES 6
+int ps_ctx_set_timing(ps_ctx* ctx, int enable);
+int ps_msm_last_stage_ms(ps_ctx* ctx, float ms[PS_MSM_STAGES]);
 
 /* ---- QAP quotient: QAP.Quotient (qap.go:151-162) + computeAggregatePoly (qap.go:164-175) ----
  * The R1CS matrices (r1cs.go:78-101: rows = gates, columns = variables) are given in CSR with
@@ -121,6 +127,9 @@ void ps_qap_free(ps_qap* q);
  * each) and h (n-1 coefficients), all device-resident.  PS_ERR_NOT_DIVISIBLE <=> "apocalypse". */
 int ps_qap_quotient(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, ps_scalars** A, ps_scalars** B,
                     ps_scalars** C, ps_scalars** h);
+
+/* Poly.Mul (algebra.go:92-105): out = a * b, len(a)+len(b)-1 coefficients (NTT product). */
+int ps_poly_mul(ps_ctx* ctx, const ps_scalars* a, const ps_scalars* b, ps_scalars** out);
 
 /* ---- whole-function drivers ---- */
 typedef struct { /* the prover's part of Groth16Setup (groth16.go:30-61) */

@@ -26,8 +26,8 @@ SYMBOLS = [
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_points_sum",
-    "ps_msm_last_info", "ps_msm_set_window",
-    "ps_qap_create", "ps_qap_free", "ps_qap_quotient",
+    "ps_msm_last_info", "ps_msm_set_window", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
+    "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
     "ps_groth16_prove", "ps_phgr13_prove",
 ]
 
@@ -101,10 +101,13 @@ def _load():
     lib.ps_points_sum.argtypes = [i, C.c_char_p, sz, C.c_char_p]
     lib.ps_msm_last_info.argtypes = [vp, C.POINTER(MsmInfo)]
     lib.ps_msm_set_window.argtypes = [vp, i]
+    lib.ps_ctx_set_timing.argtypes = [vp, i]
+    lib.ps_msm_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ps_qap_create.argtypes = [vp, sz, sz, sz, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), pp]
     lib.ps_qap_free.argtypes = [vp]
     lib.ps_qap_free.restype = None
     lib.ps_qap_quotient.argtypes = [vp, vp, vp, pp, pp, pp, pp]
+    lib.ps_poly_mul.argtypes = [vp, vp, vp, pp]
     lib.ps_groth16_prove.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_char_p, C.c_char_p]
     lib.ps_phgr13_prove.argtypes = [vp, C.POINTER(Phgr13Ek), vp, vp, C.POINTER(Phgr13Proof)]

@@ -71,6 +71,16 @@ class Context:
     def set_window(self, bits: int):
         _check(lib.ps_msm_set_window(self._h, bits))
 
+    STAGES = ("digits", "scan", "scatter", "accumulate", "fixup", "reduce")
+
+    def set_timing(self, enable: bool):
+        _check(lib.ps_ctx_set_timing(self._h, int(enable)))
+
+    def last_stage_ms(self) -> dict:
+        ms = (C.c_float * len(self.STAGES))()
+        _check(lib.ps_msm_last_stage_ms(self._h, ms))
+        return dict(zip(self.STAGES, list(ms)))
+
     def last_msm_info(self) -> dict:
         info = _lib.MsmInfo()
         _check(lib.ps_msm_last_info(self._h, C.byref(info)))
@@ -187,6 +197,12 @@ class Poly:
         h = C.c_void_p()
         _check(lib.ps_scalars_slice(self._h, first, n, C.byref(h)))
         return Poly(self.ctx, h, owner=self)
+
+    def Mul(self, p2: "Poly") -> "Poly":
+        """func (p Poly) Mul(p2 Poly) Poly (algebra.go:92-105)."""
+        h = C.c_void_p()
+        _check(lib.ps_poly_mul(self.ctx._h, self._h, p2._h, C.byref(h)))
+        return Poly(self.ctx, h)
 
     def BlindEval(self, blindedPoint: Points) -> bytes:
         """func (p Poly) BlindEval(zero Commit, blindedPoint []Commit) Commit (algebra.go:348).

@@ -80,6 +80,10 @@ struct ps_ctx {
     ps_msm_info last_info{};
     int forced_c = 0;
     QuotientCache* qcache = nullptr;
+    // optional per-stage timing (HIP events on `stream`, the stream the kernels run on)
+    bool timing = false;
+    hipEvent_t ev[PS_MSM_STAGES + 1] = {};
+    bool ev_valid = false;
 };
 
 struct Storage {  // shared device allocation behind slices
@@ -138,6 +142,7 @@ extern "C" int ps_ctx_create(int device, ps_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_flag, 64));
     c->h_pinned_cap = 64 * sizeof(Xyzz<Fp2>) + 64;
     HIP_TRY(hipHostMalloc(&c->h_pinned, c->h_pinned_cap));
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return PS_OK;
 }
@@ -150,6 +155,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
                       &c->segs, &c->wins, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -470,25 +476,36 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W + 64 > c->h_pinned_cap) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = c->stream;
+    int evi = 0;
+#define PS_STAGE_MARK() do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[evi++], st)); } while (0)
+    PS_STAGE_MARK();  // 0: start
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
     HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     hipLaunchKernelGGL(k_digits, dim3(nblocks(n)), dim3(256), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB,
                        (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->ranks.p);
+    PS_STAGE_MARK();  // 1: after memsets + digits
     hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
                        (u32*)c->bsum.p, (u64)G);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
     hipLaunchKernelGGL(k_scan_add, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (u32*)c->offs.p, (const u32*)c->bsum.p, (u64)G);
+    PS_STAGE_MARK();  // 2: after scan
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->ranks.p,
                        (const u32*)c->offs.p, (u32)n, total, (u32*)c->sorted.p);
+    PS_STAGE_MARK();  // 3: after scatter
     hipLaunchKernelGGL(k_accumulate<F>, dim3(nblocks(nthreads_acc)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,
                        (Xyzz<F>*)c->parts.p);
+    PS_STAGE_MARK();  // 4: after accumulate
     hipLaunchKernelGGL(k_fixup<F>, dim3(nblocks(G)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p);
+    PS_STAGE_MARK();  // 5: after fixup
     hipLaunchKernelGGL(k_reduce_segments<F>, dim3(nblocks(nseg_total)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
                        pl.NB, pl.SEG, nseg_total, (Xyzz<F>*)c->segs.p);
     hipLaunchKernelGGL(k_reduce_windows<F>, dim3(pl.W), dim3(256), 256 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)c->segs.p,
                        segs_per_win, (Xyzz<F>*)c->wins.p);
+    PS_STAGE_MARK();  // 6: after reduction
+#undef PS_STAGE_MARK
+    c->ev_valid = c->timing;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_pinned, c->wins.p, sizeof(Xyzz<F>) * pl.W, hipMemcpyDeviceToHost, st));
     // entry count for introspection (read back with the window sums)
@@ -572,6 +589,20 @@ extern "C" int ps_msm_i64(ps_ctx* c, const ps_points* pts, const int64_t* v, siz
 extern "C" int ps_msm_last_info(ps_ctx* c, ps_msm_info* out) {
     if (!c || !out) return fail(PS_ERR_ARG, "NULL argument");
     *out = c->last_info;
+    return PS_OK;
+}
+extern "C" int ps_ctx_set_timing(ps_ctx* c, int enable) {
+    if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
+    c->timing = enable != 0;
+    c->ev_valid = false;
+    return PS_OK;
+}
+extern "C" int ps_msm_last_stage_ms(ps_ctx* c, float* ms) {
+    if (!c || !ms) return fail(PS_ERR_ARG, "NULL argument");
+    if (!c->ev_valid) return fail(PS_ERR_ARG, "no timed MSM on this context (ps_ctx_set_timing)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[PS_MSM_STAGES]));
+    for (int i = 0; i < PS_MSM_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
     return PS_OK;
 }
 extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {

@@ -1,7 +1,363 @@
-// (filled in below) QAP quotient pipeline -- placeholder until the NTT pipeline lands.
+// QAP quotient on the reference's interpolation domain {1..n}  (qap.go:151-175).
+//
+// Reference:  A = sum_i s_i u_i(x), B, C likewise (computeAggregatePoly, qap.go:164-175), then
+// h = (A*B - C) / z with z = prod_{i=1..n}(x - i) by schoolbook Mul and an O(n^3) long division
+// (algebra.go:92-105,140-159), panic("apocalypse") when the remainder is non-zero.
+//
+// Here the same *polynomials* (bit-identical monomial coefficients; they are unique) come from:
+//   1. y_A = L.s, y_B = R.s, y_C = O.s                        CSR SpMV over Fr
+//      (A is the degree < n interpolant of y_A on {1..n}, by linearity of qap.go:168-173)
+//   2. remainder == 0  <=>  y_A[j]*y_B[j] == y_C[j] for every gate j (z has the simple roots
+//      1..n), checked point-wise: this is the "apocalypse" test
+//   3. values on {1..n} -> Newton coefficients on the nodes 1,2,..: one convolution
+//      d_k = sum_j (y_{j+1}/j!) * ((-1)^(k-j)/(k-j)!)
+//   4. Newton -> monomial: blocks of 64 by a wave-wide Horner in the Newton basis, then
+//      log2(n/64) levels  N = N_left + Z_left * N_right  with the subproduct tree
+//      Z = prod (x - i) kept in NTT form in HBM (n log n Fr elements; 288 GB makes that free)
+//   5. h = floor(A*B / z) (C = A*B mod z never needs interpolating): reversed power-series
+//      division with rev(z)^-1 mod x^(n-1) precomputed per n
+// Everything per-n (factorials, tree, z, inverse series) is built once in ps_qap_create.
 #pragma once
-#include "field.cuh"
+#include <vector>
+
+#include "ntt.cuh"
+
 namespace ps {
-struct QuotientCache;
-static inline void quotient_cache_free(QuotientCache*) {}
+
+struct QuotientCache {  // per-context NTT state
+    NttTables tabs;
+};
+static inline void quotient_cache_free(QuotientCache* q) {
+    if (!q) return;
+    if (q->tabs.fwd) (void)hipFree(q->tabs.fwd);
+    if (q->tabs.inv) (void)hipFree(q->tabs.inv);
+    delete q;
+}
+
+// ---------------------------------------------------------------------------------------
+// wave-wide kernels on blocks of 64 coefficients (lane l holds coefficient l)
+// ---------------------------------------------------------------------------------------
+__device__ inline Fr fr_shfl_up1(const Fr& v) {  // lane l gets lane l-1's value, lane 0 gets 0
+    Fr r;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u32 t = __shfl_up(v.l[j], 1, 64);
+        r.l[j] = lane == 0 ? 0u : t;
+    }
+    return r;
+}
+__device__ inline Fr fr_shfl(const Fr& v, int src) {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.l[j] = __shfl(v.l[j], src, 64);
+    return r;
+}
+__device__ inline Fr fr_from_u64(u64 v) {
+    Fr a = fr_zero();
+    a.l[0] = (u32)v;
+    a.l[1] = (u32)(v >> 32);
+    return fe_to_mont<FrParams>(a);
+}
+
+// block b: N(x) = sum_{k=0..63} d[64b+k] * prod_{i=64b+1}^{64b+k} (x - i), in place.
+// Horner in the Newton basis: poly = poly*(x - (64b+k+1)) + d[64b+k], k = 63..0.
+__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64) {
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nblocks64) return;
+    const u64 base = 64ull * wave;
+    const Fr mine = d[base + lane];
+    Fr coef = fr_zero();
+    Fr c = fr_from_u64(base + 64);  // node of step k = 63
+    const Fr one = fr_one();
+    for (int k = 63; k >= 0; k--) {
+        Fr up = fr_shfl_up1(coef);
+        Fr dk = fr_shfl(mine, k);
+        coef = fr_sub(up, fr_mul(c, coef));
+        if (lane == 0) coef = fr_add(coef, dk);
+        c = fr_sub(c, one);
+    }
+    d[base + lane] = coef;
+}
+
+// block b: lower 64 coefficients of prod_{i=64b+1}^{64b+64} (x - i)  (the x^64 term is implied)
+__global__ void __launch_bounds__(256) k_subproduct_base(Fr* __restrict__ out, u32 nblocks64) {
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= nblocks64) return;
+    const u64 base = 64ull * wave;
+    Fr coef = lane == 0 ? fr_one() : fr_zero();
+    Fr c = fr_from_u64(base + 1);
+    const Fr one = fr_one();
+    for (int k = 0; k < 64; k++) {
+        Fr up = fr_shfl_up1(coef);
+        coef = fr_sub(up, fr_mul(c, coef));
+        c = fr_add(c, one);
+    }
+    out[base + lane] = coef;
+}
+
+// ---------------------------------------------------------------------------------------
+// level kernels
+// ---------------------------------------------------------------------------------------
+// scratch[node*s + i] = i < s/2 ? data[node*s + s/2 + i] : 0
+__global__ void __launch_bounds__(256) k_level_prepare(Fr* __restrict__ scratch, const Fr* __restrict__ data, u64 total, int logs) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    u64 half = 1ull << (logs - 1);
+    u64 i = idx & ((1ull << logs) - 1);
+    scratch[idx] = i < half ? data[idx + half] : fr_zero();
+}
+// data[node*s + i] = (i < s/2 ? data[node*s + i] : 0) + scratch[node*s + i]
+__global__ void __launch_bounds__(256) k_level_combine(Fr* __restrict__ data, const Fr* __restrict__ scratch, u64 total, int logs) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    u64 half = 1ull << (logs - 1);
+    u64 i = idx & ((1ull << logs) - 1);
+    Fr s = scratch[idx];
+    data[idx] = i < half ? fr_add(data[idx], s) : s;
+}
+// full[node*2t + i] = i < t ? F[node*t + i] : (i == t ? 1 : 0)
+__global__ void __launch_bounds__(256) k_tree_expand(Fr* __restrict__ full, const Fr* __restrict__ F, u64 total2, int logt) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total2) return;
+    u64 t = 1ull << logt;
+    u64 node = idx >> (logt + 1), i = idx & (2 * t - 1);
+    full[idx] = i < t ? F[node * t + i] : (i == t ? fr_one() : fr_zero());
+}
+// prod[p*2t + i] = full[(2p)*2t + i] * full[(2p+1)*2t + i]
+__global__ void __launch_bounds__(256) k_tree_pair_mul(Fr* __restrict__ prod, const Fr* __restrict__ full, u64 total, int log2t) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    u64 p = idx >> log2t, i = idx & ((1ull << log2t) - 1);
+    prod[idx] = fr_mul(full[((2 * p) << log2t) + i], full[((2 * p + 1) << log2t) + i]);
+}
+// cyclic wrap of the monic x^(2t) term: coefficient 0 of every node carries a spurious +1
+__global__ void __launch_bounds__(256) k_tree_fix(Fr* __restrict__ F2, u64 nodes, int log2t) {
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nodes) return;
+    F2[p << log2t] = fr_sub(F2[p << log2t], fr_one());
+}
+// zhat[p*2t + i] = full[(2p)*2t + i]  (left children only)
+__global__ void __launch_bounds__(256) k_tree_take_left(Fr* __restrict__ zhat, const Fr* __restrict__ full, u64 total, int log2t) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    u64 p = idx >> log2t, i = idx & ((1ull << log2t) - 1);
+    zhat[idx] = full[((2 * p) << log2t) + i];
+}
+
+// ---------------------------------------------------------------------------------------
+// per-proof kernels
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spmv(const u32* __restrict__ row_ptr, const u32* __restrict__ col,
+                                              const Fr* __restrict__ val, const Fr* __restrict__ x, Fr* __restrict__ y, u32 n) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    Fr acc = fr_zero();
+    for (u32 e = row_ptr[r]; e < row_ptr[r + 1]; e++) acc = fr_add(acc, fr_mul(val[e], x[col[e]]));
+    y[r] = acc;
+}
+__global__ void __launch_bounds__(256) k_check_gates(const Fr* __restrict__ yA, const Fr* __restrict__ yB,
+                                                     const Fr* __restrict__ yC, u32 n, u32* __restrict__ flag) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    if (!fe_eq<FrParams>(fr_mul(yA[r], yB[r]), yC[r])) atomicOr(flag, 1u);
+}
+// out[j] = j < n ? y[j] * invfact[j] : 0   for j < total
+__global__ void __launch_bounds__(256) k_scale_pad(Fr* __restrict__ out, const Fr* __restrict__ y, const Fr* __restrict__ invfact,
+                                                   u64 n, u64 total) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    out[j] = j < n ? fr_mul(y[j], invfact[j]) : fr_zero();
+}
+// q[i] = i < cnt ? P[top - i] : 0, i < total
+__global__ void __launch_bounds__(256) k_rev_take(Fr* __restrict__ q, const Fr* __restrict__ P, u64 top, u64 cnt, u64 total) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    q[i] = i < cnt ? P[top - i] : fr_zero();
+}
+// t[i] = (i == 0 ? 2 : 0) - t[i]
+__global__ void __launch_bounds__(256) k_two_minus(Fr* __restrict__ t, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = fe_neg<FrParams>(t[i]);
+    if (i == 0) { Fr one = fr_one(); v = fr_add(v, fr_add(one, one)); }
+    t[i] = v;
+}
+__global__ void __launch_bounds__(64) k_set_one(Fr* __restrict__ p, u64 idx) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = fr_one();
+}
+
+// ---------------------------------------------------------------------------------------
+// per-n tables
+// ---------------------------------------------------------------------------------------
+struct QapTables {
+    u64 n = 0, np = 0;
+    int lognp = 0;
+    Fr* invfact = nullptr;       // np : 1/j!
+    Fr* vhat = nullptr;          // 2np: NTT of v_j = (-1)^j / j!
+    std::vector<Fr*> zhat;       // [logs] -> np elements, logs = 7..lognp
+    Fr* z = nullptr;             // n+1 coefficients of prod (x - i), i = 1..n
+    Fr* ghat = nullptr;          // NTT_{2^ph} of rev(z)^-1 mod x^(n-1)
+    int ph = 0, pp = 0;          // log sizes of the division / product transforms
+    // work buffers
+    Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
+    std::vector<void*> owned;
+    void free_all() {
+        for (void* p : owned) (void)hipFree(p);
+        owned.clear();
+        zhat.clear();
+    }
+};
+
+#define QT_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
+
+static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
+    hipError_t e = hipMalloc((void**)p, sizeof(Fr) * (count ? count : 1));
+    if (e == hipSuccess) qt.owned.push_back(*p);
+    return e;
+}
+
+// Newton coefficients (np of them, zero beyond the true length) -> monomial coefficients, in place
+static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, const QapTables& qt, Fr* data, Fr* scratch) {
+    const u64 np = qt.np;
+    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64));
+    for (int logs = 7; logs <= qt.lognp; logs++) {
+        hipLaunchKernelGGL(k_level_prepare, dim3(nblk(np)), dim3(256), 0, st, scratch, data, np, logs);
+        QT_TRY(ntt_run<false>(tabs, st, scratch, np, logs));
+        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(np)), dim3(256), 0, st, scratch, scratch, qt.zhat[logs], np);
+        QT_TRY(ntt_run<true>(tabs, st, scratch, np, logs));
+        hipLaunchKernelGGL(k_level_combine, dim3(nblk(np)), dim3(256), 0, st, data, scratch, np, logs);
+    }
+    return hipGetLastError();
+}
+
+// values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
+static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y) {
+    const u64 np = qt.np, n = qt.n;
+    hipLaunchKernelGGL(k_scale_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, y, qt.invfact, n, 2 * np);
+    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, qt.lognp + 1));
+    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, qt.t1, qt.vhat, 2 * np);
+    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, qt.lognp + 1));
+    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(np)), dim3(256), 0, st, qt.data, qt.t1, n, np);
+    return newton_to_monomial(tabs, st, qt, qt.data, qt.scratch);
+}
+
+// h = floor(A*B / z): n-1 coefficients into h_out (Montgomery); A, B have n coefficients
+static inline hipError_t quotient_from_AB(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* A, const Fr* B, Fr* h_out) {
+    const u64 n = qt.n;
+    if (n < 2) return hipSuccess;
+    const u64 Sp = 1ull << qt.pp, Sh = 1ull << qt.ph;
+    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(Sp)), dim3(256), 0, st, qt.pa, A, n, Sp);
+    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(Sp)), dim3(256), 0, st, qt.pb, B, n, Sp);
+    QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sp, qt.pp));
+    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sp, qt.pp));
+    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(Sp)), dim3(256), 0, st, qt.pa, qt.pa, qt.pb, Sp);
+    QT_TRY(ntt_run<true>(tabs, st, qt.pa, Sp, qt.pp));
+    // q_i = P_{2n-2-i}, i < n-1
+    hipLaunchKernelGGL(k_rev_take, dim3(nblk(Sh)), dim3(256), 0, st, qt.pb, qt.pa, 2 * n - 2, n - 1, Sh);
+    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sh, qt.ph));
+    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(Sh)), dim3(256), 0, st, qt.pb, qt.pb, qt.ghat, Sh);
+    QT_TRY(ntt_run<true>(tabs, st, qt.pb, Sh, qt.ph));
+    // h_{n-2-i} = (q*g)_i
+    hipLaunchKernelGGL(k_rev_take, dim3(nblk(n - 1)), dim3(256), 0, st, h_out, qt.pb, n - 2, n - 1, n - 1);
+    return hipGetLastError();
+}
+
+// Build every per-n table.  Host arithmetic is limited to the factorial table (n' field
+// multiplications and one inversion, with the library's own host-compiled field code).
+static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTables& qt, u64 n) {
+    qt.n = n;
+    int lg = ilog2_ceil(n < 64 ? 64 : n);
+    qt.lognp = lg;
+    qt.np = 1ull << lg;
+    const u64 np = qt.np;
+    qt.pp = ilog2_ceil(2 * n - 1);
+    qt.ph = n >= 2 ? ilog2_ceil(2 * (n - 1) - 1 > 0 ? 2 * (n - 1) - 1 : 1) : 0;
+    QT_TRY(ntt_tables_ensure(tabs, lg + 1, st));
+    const u64 Sp = 1ull << qt.pp, Sh = 1ull << qt.ph;
+    const u64 big = 2 * np > Sp ? 2 * np : Sp;
+    QT_TRY(qt_alloc(qt, &qt.invfact, np));
+    QT_TRY(qt_alloc(qt, &qt.vhat, 2 * np));
+    QT_TRY(qt_alloc(qt, &qt.t1, big));
+    QT_TRY(qt_alloc(qt, &qt.data, np));
+    QT_TRY(qt_alloc(qt, &qt.scratch, big));
+    QT_TRY(qt_alloc(qt, &qt.pa, big));
+    QT_TRY(qt_alloc(qt, &qt.pb, big));
+    QT_TRY(qt_alloc(qt, &qt.z, n + 1));
+    QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
+    // ---- factorials (host) ----
+    {
+        std::vector<Fr> inv(np), v(np);
+        Fr f = fr_one(), jm = fr_zero();
+        const Fr one = fr_one();
+        std::vector<Fr> fact(np);
+        for (u64 j = 0; j < np; j++) {
+            if (j > 0) { jm = fr_add(jm, one); f = fr_mul(f, jm); }
+            fact[j] = f;
+        }
+        Fr finv = fe_inv<FrParams>(fact[np - 1]);
+        // walk down: 1/(j-1)! = (1/j!) * j
+        Fr jj = jm;
+        for (u64 j = np; j-- > 0;) {
+            inv[j] = finv;
+            finv = fr_mul(finv, jj);
+            jj = fr_sub(jj, one);
+        }
+        for (u64 j = 0; j < np; j++) v[j] = (j & 1) ? fe_neg<FrParams>(inv[j]) : inv[j];
+        QT_TRY(hipMemcpyAsync(qt.invfact, inv.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.t1, v.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
+        QT_TRY(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.vhat, qt.t1, np, 2 * np);
+    QT_TRY(ntt_run<false>(tabs, st, qt.vhat, 2 * np, lg + 1));
+    // ---- subproduct tree ----
+    qt.zhat.assign(lg + 1, nullptr);
+    Fr *F = qt.data, *F2 = qt.scratch, *full = qt.t1;  // F: np, full: 2np, F2: np
+    hipLaunchKernelGGL(k_subproduct_base, dim3(nblk(np)), dim3(256), 0, st, F, (u32)(np / 64));
+    for (int logt = 6; logt < lg; logt++) {
+        const int log2t = logt + 1;
+        hipLaunchKernelGGL(k_tree_expand, dim3(nblk(2 * np)), dim3(256), 0, st, full, F, 2 * np, logt);
+        QT_TRY(ntt_run<false>(tabs, st, full, 2 * np, log2t));
+        Fr* zh;
+        QT_TRY(qt_alloc(qt, &zh, np));
+        qt.zhat[log2t] = zh;
+        hipLaunchKernelGGL(k_tree_take_left, dim3(nblk(np)), dim3(256), 0, st, zh, full, np, log2t);
+        hipLaunchKernelGGL(k_tree_pair_mul, dim3(nblk(np)), dim3(256), 0, st, F2, full, np, log2t);
+        QT_TRY(ntt_run<true>(tabs, st, F2, np, log2t));
+        hipLaunchKernelGGL(k_tree_fix, dim3(nblk(np >> log2t)), dim3(256), 0, st, F2, np >> log2t, log2t);
+        Fr* tmp = F; F = F2; F2 = tmp;
+    }
+    // ---- z = prod_{i=1..n} (x - i) ----
+    if (n == np) {  // F now holds the single top node: lower np coefficients, monic
+        QT_TRY(hipMemcpyAsync(qt.z, F, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, qt.z, n);
+    } else {  // z is the Newton basis polynomial N_n: convert the unit vector e_n
+        QT_TRY(hipMemsetAsync(qt.pa, 0, sizeof(Fr) * np, st));
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, qt.pa, n);
+        QT_TRY(newton_to_monomial(tabs, st, qt, qt.pa, qt.pb));
+        QT_TRY(hipMemcpyAsync(qt.z, qt.pa, sizeof(Fr) * (n + 1), hipMemcpyDeviceToDevice, st));
+    }
+    // ---- g = rev(z)^-1 mod x^(n-1) by Newton iteration ----
+    if (n >= 2) {
+        const u64 m = n - 1;
+        Fr *f = qt.data, *g = qt.pa, *t = qt.pb;  // f: np >= m ; g, t: big
+        hipLaunchKernelGGL(k_rev_take, dim3(nblk(m)), dim3(256), 0, st, f, qt.z, n, m, m);  // f_i = z_{n-i}
+        QT_TRY(hipMemsetAsync(g, 0, sizeof(Fr) * big, st));
+        hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, g, (u64)0);
+        for (u64 cur = 1; cur < m;) {
+            u64 nxt = 2 * cur < m ? 2 * cur : m;
+            QT_TRY(poly_mul_dev(tabs, st, f, nxt, g, cur, t, nxt, qt.t1, qt.scratch));
+            hipLaunchKernelGGL(k_two_minus, dim3(nblk(nxt)), dim3(256), 0, st, t, nxt);
+            QT_TRY(poly_mul_dev(tabs, st, g, cur, t, nxt, g, nxt, qt.t1, qt.scratch));
+            cur = nxt;
+        }
+        hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(Sh)), dim3(256), 0, st, qt.ghat, g, m, Sh);
+        QT_TRY(ntt_run<false>(tabs, st, qt.ghat, Sh, qt.ph));
+    }
+    QT_TRY(hipStreamSynchronize(st));
+    return hipGetLastError();
+}
+
 }  // namespace ps

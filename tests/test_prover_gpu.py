@@ -1,0 +1,184 @@
+"""GPU parity of the QAP quotient pipeline and the two provers (through the C ABI) against the
+oracle's restatement of qap.go / groth16.go / pinochio.go.  Bit-exact on every coefficient and
+every proof byte; the oracle computes the aggregate polynomials by Lagrange interpolation and h by
+the reference's own schoolbook Mul + long division Div2, the GPU by SpMV + Newton-basis
+interpolation + NTT products + power-series division -- agreement is the parity claim.
+"""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x706C6179736E61726B & 0xFFFFFFFFFFFFFFFF
+
+
+def _upload_circuit(ps_api, ctx, c):
+    return ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (2, 3), (5, 4), (64, 64), (100, 29), (1000, 1000), (4097, 33)])
+def test_poly_mul_matches_schoolbook(ps_api, ctx, co, pr, na, nb):
+    """Poly.Mul (algebra.go:92-105); includes TestAlgebraPolyMul's fixed case shape."""
+    rng = pr.SplitMix64(SEED + na * 7 + nb)
+    a = [rng.fr() for _ in range(na)]
+    b = [rng.fr() for _ in range(nb)]
+    got = ps_api.Poly.upload(ctx, a).Mul(ps_api.Poly.upload(ctx, b)).download()
+    assert got == co.poly_mul(a, b)
+
+
+def test_poly_mul_reference_fixed_case(ps_api, ctx):
+    """TestAlgebraPolyMul (algebra_test.go:76-104): (1+2x)(3+x^2) = 3+6x+x^2+2x^3."""
+    got = ps_api.Poly.upload(ctx, [1, 2]).Mul(ps_api.Poly.upload(ctx, [3, 0, 1])).download()
+    assert got == [3, 6, 1, 2]
+
+
+def test_quotient_toy_matches_survey_fixture(ps_api, ctx, pr):
+    """Config #1 (x^3+x+5=35): h, A from SURVEY.md 8c / tests/golden; TestGroth16TrustedSetup's
+    length pin deg h == n-2 (groth16_test.go:16-19)."""
+    from oracle import restate as rs
+
+    c, wit = rs.toy_circuit()
+    q = _upload_circuit(ps_api, ctx, c)
+    sol = ps_api.Poly.from_values(ctx, wit)
+    A, B, Cc, h = q.computeAggregatePoly(sol)
+    assert len(h) == q.nbGates - 1
+    assert h.download() == [
+        0x4D491A377113A8DACCD13AB0066BE558E27E6D5755543D54AAAAAAA9FFFFFFFD,
+        0x46D8580827A75AC891152076B08D923C24F3E43AB8E28D8D9C71C71BD5555567,
+        0x0CE1845E92D89C2477783472ABBCA6397B15123938E35F8E1C71C71C55555552,
+    ]
+    ref = pr.to_qap(pr.create_r1cs())
+    assert (A.download(), B.download(), Cc.download()) == tuple(pr.compute_aggregate_poly(ref, wit))
+    assert q.Quotient(sol).download() == pr.quotient(ref, wit)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 17, 63, 64, 65, 100, 128, 200, 256, 511, 512])
+def test_quotient_matches_reference_algorithm(ps_api, ctx, co, pr, n):
+    """A, B, C, h for the tiled synthetic circuit against interpolation + Mul + Div2."""
+    from oracle import restate as rs
+
+    c, sol = rs.synthetic_circuit(n, x0=3 + n)
+    q = _upload_circuit(ps_api, ctx, c)
+    A, B, Cc, h = q.computeAggregatePoly(ps_api.Poly.upload(ctx, sol))
+    want = co.quotient_from_values(*c.values(sol))
+    assert A.download() == want[0]
+    assert B.download() == want[1]
+    assert Cc.download() == want[2]
+    assert h.download() == want[3]
+
+
+def test_quotient_apocalypse_and_sanity(ps_api, ctx, pr):
+    """panic("apocalypse") (qap.go:158-160) on a witness that violates one gate; sanityCheck
+    (qap.go:177-189) on a wrong-length solution."""
+    from oracle import restate as rs
+
+    c, sol = rs.synthetic_circuit(37)
+    q = _upload_circuit(ps_api, ctx, c)
+    bad = list(sol)
+    bad[5] = (bad[5] + 1) % pr.R
+    with pytest.raises(ps_api.Apocalypse):
+        q.Quotient(ps_api.Poly.upload(ctx, bad))
+    with pytest.raises(ps_api.PlaysnarkError):
+        q.Quotient(ps_api.Poly.upload(ctx, sol[:-1]))
+    assert len(q.Quotient(ps_api.Poly.upload(ctx, sol))) == 36
+
+
+def test_quotient_large_n_properties(ps_api, ctx, co, pr):
+    """n = 2^14: size-independent checks.  A(j) = (L.s)_j at sampled gates (TestAlgebraInterpolate's
+    property), and A(t)B(t) - C(t) = h(t) z(t) at a random point (the QAP identity the reference
+    checks in the clear, pinocchio_test.go:147-155)."""
+    from oracle import restate as rs
+
+    n = 1 << 14
+    c, sol = rs.synthetic_circuit(n)
+    q = _upload_circuit(ps_api, ctx, c)
+    A, B, Cc, h = (p.download() for p in q.computeAggregatePoly(ps_api.Poly.upload(ctx, sol)))
+    yA, yB, yC = c.values(sol)
+    for j in (1, 2, 3, 1000, n // 2, n - 1, n):
+        assert co.poly_eval(A, j) == yA[j - 1]
+        assert co.poly_eval(B, j) == yB[j - 1]
+        assert co.poly_eval(Cc, j) == yC[j - 1]
+    t = pr.SplitMix64(SEED + 5).fr()
+    _, zt = rs.lagrange_at(n, t)
+    lhs = (co.poly_eval(A, t) * co.poly_eval(B, t) - co.poly_eval(Cc, t)) % pr.R
+    assert lhs == co.poly_eval(h, t) * zt % pr.R
+    assert len(h) == n - 1
+
+
+def _points(ps_api, ctx, group, raw):
+    return ps_api.Points.upload(ctx, group, raw)
+
+
+def _groth16_pk(ps_api, ctx, tr):
+    return ps_api.Groth16Setup(
+        tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2,
+        _points(ps_api, ctx, ps_api.G1, tr.Xi), _points(ps_api, ctx, ps_api.G2, tr.Xi2),
+        _points(ps_api, ctx, ps_api.G1, tr.NioLP), _points(ps_api, ctx, ps_api.G1, tr.XiT),
+    )
+
+
+def test_groth16_toy_proof_bit_identical(ps_api, ctx, co, pr):
+    """Config #1 end to end: TestGroth16ProofGen's dlog identities (groth16_test.go:32-107) and
+    byte equality with the literal nested-sumBlind restatement."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 16)
+    c, wit = rs.toy_circuit()
+    tox = [rng.fr() for _ in range(5)]
+    r, s = rng.fr(), rng.fr()
+    tr = rs.groth16_setup(c, *tox)
+    sol = [pr.fr(v) for v in wit]
+    want = rs.groth16_prove(tr, c, sol, r, s)
+    assert rs.groth16_dlog_check(tr, c, sol, want) == (True, True, True)
+    q = _upload_circuit(ps_api, ctx, c)
+    proof = ps_api.Groth16Prove(_groth16_pk(ps_api, ctx, tr), q, ps_api.Poly.from_values(ctx, wit), r, s)
+    assert (proof.A, proof.B, proof.C) == (want.A, want.B, want.C)
+    # literal reference form (per-variable polynomials, nested loops) from the Python twin
+    ql = pr.to_qap(pr.create_r1cs())
+    lit = pr.groth16_prove(pr.groth16_setup(ql, *tox), ql, wit, r, s)
+    assert (proof.A, proof.B, proof.C) == (co.G1.to_b(lit.A), co.G2.to_b(lit.B), co.G1.to_b(lit.C))
+
+
+@pytest.mark.parametrize("n", [7, 64, 300])
+def test_groth16_synthetic_proof_bit_identical(ps_api, ctx, co, pr, n):
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 160 + n)
+    c, sol = rs.synthetic_circuit(n)
+    tr = rs.groth16_setup(c, *[rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    want = rs.groth16_prove(tr, c, sol, r, s, fast=True)
+    assert rs.groth16_dlog_check(tr, c, sol, want) == (True, True, True)
+    q = _upload_circuit(ps_api, ctx, c)
+    proof = ps_api.Groth16Prove(_groth16_pk(ps_api, ctx, tr), q, ps_api.Poly.upload(ctx, sol), r, s)
+    assert (proof.A, proof.B, proof.C) == (want.A, want.B, want.C)
+
+
+def _phgr13_ek(ps_api, ctx, ek):
+    kw = {}
+    for f in ps_api.PHGR13EvalKey.FIELDS:
+        kw[f] = _points(ps_api, ctx, ps_api.G2 if f == "ws" else ps_api.G1, getattr(ek, f))
+    return ps_api.PHGR13EvalKey(**kw)
+
+
+@pytest.mark.parametrize("n", [4, 50, 256])
+def test_phgr13_proof_bit_identical(ps_api, ctx, co, pr, n):
+    """PHGR13Prove is deterministic (no prover randomness): all 8 elements byte-equal.
+    n = 4 is the toy circuit of TestPinocchioProofValidDivision (pinocchio_test.go:23-29)."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 13 + n)
+    if n == 4:
+        c, wit = rs.toy_circuit()
+        sol = [pr.fr(v) for v in wit]
+        sol_dev = ps_api.Poly.from_values(ctx, wit)
+    else:
+        c, sol = rs.synthetic_circuit(n)
+        sol_dev = ps_api.Poly.upload(ctx, sol)
+    setup = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    want = rs.phgr13_prove(setup.EK, c, sol, fast=n > 16)
+    q = _upload_circuit(ps_api, ctx, c)
+    proof = ps_api.PHGR13Prove(_phgr13_ek(ps_api, ctx, setup.EK), q, sol_dev)
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(proof, f) == getattr(want, f), f
+    # hs == h(s)*G  (pinocchio_test.go:33-44)
+    assert proof.hs == co.G1.to_b(co.G1.mul(pr.poly_eval(want.h, setup.t.s)))
