@@ -385,16 +385,11 @@ extern "C" void ps_points_free(ps_points* p) {
 // ---------------------------------------------------------------------------------------
 // host-side folding of window sums / partial sums (same field code, compiled for the host)
 // ---------------------------------------------------------------------------------------
-static void fp_to_be48_host(uint8_t* p, const Fp& a) {
-    Fp v = fe_from_mont<FpParams>(a);
-    limbs_to_be<12>(p, v.l);
-}
+static void fp_to_be48_host(uint8_t* p, const Fp& a) { fp_to_be48(p, a); }
 static bool fp_from_be48_host(Fp& out, const uint8_t* p) {
-    Fp a;
-    limbs_from_be<12>(a.l, p);
-    if (!fe_is_canonical<FpParams>(a.l)) return false;
-    out = fe_to_mont<FpParams>(a);
-    return true;
+    bool ok = true;
+    out = fp_from_be48(p, ok);
+    return ok;
 }
 static void write_affine(uint8_t* out, const Xyzz<Fp>& acc) {
     Fp x, y;
@@ -419,7 +414,7 @@ static void write_affine(uint8_t* out, const Xyzz<Fp2>& acc) {
     fp_to_be48_host(out + 144, y.c0);
 }
 static bool read_affine(Affine<Fp>& a, const uint8_t* p) {
-    if (p[0] & 0x40) { a.x = fe_zero<FpParams>(); a.y = fe_zero<FpParams>(); return true; }
+    if (p[0] & 0x40) { a.x = fp_zero(); a.y = fp_zero(); return true; }
     if (p[0] & 0xE0) return false;
     if (!fp_from_be48_host(a.x, p) || !fp_from_be48_host(a.y, p + 48)) return false;
     return affine_on_curve<Fp>(a);

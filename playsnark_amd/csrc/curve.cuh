@@ -8,6 +8,11 @@
 // P + (-P)) is handled, because bit-exactness with the reference's serial
 // Point.Mul/Point.Add loop (algebra.go:355-357) must hold for *all* inputs, including
 // repeated points and adversarial scalars.
+//
+// Lazy-limb discipline (field.cuh): coordinates stored in an accumulator are kept at limb class
+// ~1 by f_norm() on X3 / Y3 (ZZ, ZZZ are multiplication outputs); every product below then sees
+// operand classes whose product is <= 4 and values <= 6p, inside f_mul's contract (<= 8, <= 16p).
+// The rare exceptional branches are out of line so the hot loop stays small.
 #pragma once
 #include "field.cuh"
 
@@ -45,18 +50,24 @@ PS_INL Xyzz<F> xyzz_from_affine(const F& x, const F& y) {
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PS_COLD __host__ __device__ __attribute__((noinline))
+#else
+#define PS_COLD PS_HD inline
+#endif
+
 // 2*(x, y) for an affine point (mdbl-2008-s-1)
 template <class F>
-PS_HD inline Xyzz<F> xyzz_dbl_affine(const F& x, const F& y) {
+PS_COLD Xyzz<F> xyzz_dbl_affine(const F& x, const F& y) {
     F u = f_add(y, y);
     F v = f_sqr(u);
     F w = f_mul(u, v);
     F s = f_mul(x, v);
     F xx = f_sqr(x);
-    F m = f_add(f_add(xx, xx), xx);
+    F m = f_norm(f_add(f_add(xx, xx), xx));
     Xyzz<F> r;
-    r.x = f_sub(f_sub(f_sqr(m), s), s);
-    r.y = f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, y));
+    r.x = f_norm(f_sub(f_sub(f_sqr(m), s), s));
+    r.y = f_norm(f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, y)));
     r.zz = v;
     r.zzz = w;
     return r;
@@ -64,17 +75,17 @@ PS_HD inline Xyzz<F> xyzz_dbl_affine(const F& x, const F& y) {
 
 // 2*P (dbl-2008-s-1, a = 0)
 template <class F>
-PS_HD inline Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+PS_COLD Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
     if (xyzz_is_identity(p)) return p;
     F u = f_add(p.y, p.y);
     F v = f_sqr(u);
     F w = f_mul(u, v);
     F s = f_mul(p.x, v);
     F xx = f_sqr(p.x);
-    F m = f_add(f_add(xx, xx), xx);
+    F m = f_norm(f_add(f_add(xx, xx), xx));
     Xyzz<F> r;
-    r.x = f_sub(f_sub(f_sqr(m), s), s);
-    r.y = f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, p.y));
+    r.x = f_norm(f_sub(f_sub(f_sqr(m), s), s));
+    r.y = f_norm(f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, p.y)));
     r.zz = f_mul(v, p.zz);
     r.zzz = f_mul(w, p.zzz);
     return r;
@@ -99,8 +110,8 @@ PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
     F pp = f_sqr(p);
     F ppp = f_mul(p, pp);
     F q = f_mul(acc.x, pp);
-    F x3 = f_sub(f_sub(f_sub(f_sqr(r), ppp), q), q);
-    F y3 = f_sub(f_mul(r, f_sub(q, x3)), f_mul(acc.y, ppp));
+    F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), q), q));
+    F y3 = f_norm(f_sub(f_mul(r, f_sub(q, x3)), f_mul(acc.y, ppp)));
     acc.zz = f_mul(acc.zz, pp);
     acc.zzz = f_mul(acc.zzz, ppp);
     acc.x = x3;
@@ -129,8 +140,8 @@ PS_HD inline void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
     F pp = f_sqr(p);
     F ppp = f_mul(p, pp);
     F qq = f_mul(u1, pp);
-    F x3 = f_sub(f_sub(f_sub(f_sqr(r), ppp), qq), qq);
-    F y3 = f_sub(f_mul(r, f_sub(qq, x3)), f_mul(s1, ppp));
+    F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), qq), qq));
+    F y3 = f_norm(f_sub(f_mul(r, f_sub(qq, x3)), f_mul(s1, ppp)));
     acc.zz = f_mul(f_mul(acc.zz, q.zz), pp);
     acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), ppp);
     acc.x = x3;
@@ -174,8 +185,8 @@ PS_HD inline bool xyzz_to_affine(const Xyzz<F>& p, F& x, F& y) {
     F t = f_inv(f_mul(p.zz, p.zzz));
     F izz = f_mul(t, p.zzz);
     F izzz = f_mul(t, p.zz);
-    x = f_mul(p.x, izz);
-    y = f_mul(p.y, izzz);
+    x = fp_canon(f_mul(p.x, izz));  // stored affine coordinates are always canonical
+    y = fp_canon(f_mul(p.y, izzz));
     return true;
 }
 

@@ -1,9 +1,15 @@
 // BLS12-381 prime-field arithmetic for gfx950 (and for the host-side glue of the same library).
 //
-// Representation: little-endian 32-bit limbs (Fp: 12, Fr: 8), Montgomery form, canonical
-// (< modulus).  CDNA4 has no 64x64 multiplier; the widest integer multiply is
-// v_mad_u64_u32 (32x32+64 -> 64), so 32-bit limbs are the native width.  All loops are
-// fully unrolled with compile-time indices so every element lives in VGPRs (no scratch).
+// Two representations, chosen from measured gfx950 instruction rates (profiles/r01_microbench_valu.txt):
+// v_mad_u64_u32 / v_mad_i64_i32 run at half rate (~28 T lane-ops/s chip-wide) while every carry
+// instruction (v_addc_co_u32, v_lshl_add_u64) costs almost as much as a multiply and needs
+// software wait states behind an SGPR carry.
+//   Fp (381 bit, the MSM's coordinate field): UNSATURATED -- 14 signed limbs of 28 bits,
+//      Montgomery R = 2^392.  Products accumulate in 64-bit columns with no carry handling
+//      (14 * 2^58 fits), add/sub are 14 independent v_add_u32, reduction is lazy.  One
+//      multiplication is 392 mads + ~110 cheap ops, fully inlined (no call ABI, no scratch).
+//   Fr (255 bit, NTT / scalars): saturated 8 x 32-bit limbs, CIOS Montgomery (R = 2^256).
+// All loops are fully unrolled with compile-time indices so elements live in VGPRs.
 //
 // This is product code: it replaces, for the hot path, the arithmetic the reference gets
 // from kilic/bls12-381 through kyber (call sites algebra.go:100-101,111-112,356;
@@ -46,7 +52,6 @@ struct Fe {
     static constexpr int N = P::N;
     u32 l[P::N];
 };
-typedef Fe<FpParams> Fp;
 typedef Fe<FrParams> Fr;
 
 // ---------------------------------------------------------------------------------------
@@ -285,48 +290,288 @@ PS_HD inline void limbs_to_be(uint8_t* b, const u32* l) {
     }
 }
 
+
+// =======================================================================================
+// Fp: unsaturated 14 x 28-bit signed limbs, Montgomery R = 2^392
+// =======================================================================================
+// Value V = sum l[i] * 2^(28 i).  Limbs are int32 and may be negative or exceed 28 bits
+// ("lazy"): add/sub/neg never carry.  Magnitude class c means |l[i]| < c * 2^28.
+//   * f_mul(a, b) needs class(a) * class(b) <= 8 and |A|, |B| <= 16 p; its result has limbs
+//     0..12 in [0, 2^28), a small signed top limb, and value in (-p/8, 9p/8)   ("class 1").
+//   * f_norm() is one parallel carry-save step that brings any class <= 8 value back to class ~1
+//     without changing V.
+//   * f_is_zero / f_eq work modulo p for |V| < 3p (every call site passes differences of
+//     class-1 values or multiplication results).
+typedef int32_t i32;
+typedef int64_t i64;
+
+struct Fp {
+    static constexpr int L = 14;
+    i32 l[14];
+};
+constexpr int FP_L = 14;
+constexpr u32 FP_MASK = (1u << 28) - 1u;
+constexpr u32 FP_INV28 = PS_FP28_INV;
+
+PS_HD constexpr i32 fp_mod28(int i) { constexpr i32 v[FP_L] = PS_FP28_MOD; return v[i]; }
+PS_HD constexpr i32 fp_r1_28(int i) { constexpr i32 v[FP_L] = PS_FP28_R1; return v[i]; }
+PS_HD constexpr i32 fp_r2_28(int i) { constexpr i32 v[FP_L] = PS_FP28_R2; return v[i]; }
+
+PS_INL Fp fp_zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = 0;
+    return r;
+}
+PS_INL Fp fp_one() {  // Montgomery one
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = fp_r1_28(i);
+    return r;
+}
+PS_INL Fp f_add(const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+PS_INL Fp f_sub(const Fp& a, const Fp& b) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+PS_INL Fp f_neg(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = -a.l[i];
+    return r;
+}
+// one parallel carry-save step: limbs 0..12 into [0, 2^28) + a small carry, value unchanged
+PS_INL Fp f_norm(const Fp& a) {
+    Fp r;
+    r.l[0] = (i32)((u32)a.l[0] & FP_MASK);
+#pragma unroll
+    for (int i = 1; i < FP_L - 1; i++) r.l[i] = (i32)((u32)a.l[i] & FP_MASK) + (a.l[i - 1] >> 28);
+    r.l[FP_L - 1] = a.l[FP_L - 1] + (a.l[FP_L - 2] >> 28);
+    return r;
+}
+// full sequential carry: limbs 0..12 in [0, 2^28), signed top limb; unique for a given V
+PS_INL Fp fp_propagate(const Fp& a) {
+    Fp r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < FP_L - 1; i++) {
+        i32 t = a.l[i] + c;
+        r.l[i] = (i32)((u32)t & FP_MASK);
+        c = t >> 28;
+    }
+    r.l[FP_L - 1] = a.l[FP_L - 1] + c;
+    return r;
+}
+
+// Montgomery product, product scanning: column k sums a[i]*b[k-i] and m[i]*p[k-i] in one signed
+// 64-bit accumulator (v_mad_i64_i32 chains), m[k] = -acc/p mod 2^28 clears the low 28 bits.
+PS_INL Fp f_mul(const Fp& a, const Fp& b) {
+    Fp r;
+    i32 m[FP_L];
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < FP_L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        m[k] = (i32)(((u32)acc * FP_INV28) & FP_MASK);
+        acc += (i64)m[k] * (i64)fp_mod28(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = FP_L; k < 2 * FP_L - 1; k++) {
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        r.l[k - FP_L] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    r.l[FP_L - 1] = (i32)acc;
+    return r;
+}
+PS_INL Fp f_sqr(const Fp& a) { return f_mul(a, a); }  // the compiler folds the symmetric products
+
+// Out-of-line copy for code paths where ten inlined multiplications per group operation would
+// not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
+#if defined(__HIP_DEVICE_COMPILE__)
+__host__ __device__ __attribute__((noinline)) Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }
+#else
+PS_HD inline Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }
+#endif
+
+// V == 0 (mod p)?  Valid for any lazy value with class <= 8 and |V| <= 16p.
+// Filter: V = k*p with |k| <= 16 forces (V mod 2^28) * p^-1 = k (mod 2^28); computed from limb 0
+// alone (higher limbs are multiples of 2^28).  Anything else is non-zero -- the common case, ~6
+// instructions.  Survivors (probability 2^-23) take the exact path: one Montgomery reduction
+// brings V into (-p/8, 9p/8), where zero means the carried form equals 0 or p.
+PS_HD inline bool fp_is_zero_exact(const Fp& a) {
+    Fp one = fp_zero();
+    one.l[0] = 1;
+    Fp t = fp_propagate(fp_mul_call(a, one));
+    u32 d0 = 0, dp = 0;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) {
+        d0 |= (u32)t.l[i];
+        dp |= (u32)(t.l[i] ^ fp_mod28(i));
+    }
+    return d0 == 0 || dp == 0;
+}
+PS_INL bool fp_all_zero(const Fp& a) {  // every limb literally zero (canonical inputs)
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) o |= (u32)a.l[i];
+    return o == 0;
+}
+PS_INL bool f_is_zero(const Fp& a) {
+    if (fp_all_zero(a)) return true;
+    constexpr u32 PINV_POS = ((1u << 28) - FP_INV28) & FP_MASK;  // p^-1 mod 2^28
+    u32 q = (((u32)a.l[0] & FP_MASK) * PINV_POS) & FP_MASK;
+    if (q > 32u && q < (1u << 28) - 32u) return false;
+    return fp_is_zero_exact(a);
+}
+PS_INL bool f_eq(const Fp& a, const Fp& b) { return f_is_zero(f_sub(a, b)); }
+
+// canonical representative in [0, p), limbs in [0, 2^28): for V in (-2p, 3p)
+PS_INL Fp fp_canon(const Fp& a) {
+    Fp t = fp_propagate(a);
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {  // negative -> add p (twice covers (-2p, 0))
+        bool negv = t.l[FP_L - 1] < 0;
+        Fp u;
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) u.l[i] = t.l[i] + (negv ? fp_mod28(i) : 0);
+        t = fp_propagate(u);
+    }
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {  // >= p -> subtract p (twice covers [p, 3p))
+        Fp u;
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) u.l[i] = t.l[i] - fp_mod28(i);
+        u = fp_propagate(u);
+        bool ge = u.l[FP_L - 1] >= 0;
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) t.l[i] = ge ? u.l[i] : t.l[i];
+    }
+    return t;
+}
+
+// plain 384-bit little-endian words (12 x u32) <-> 28-bit limbs
+PS_INL Fp fp_from_words12(const u32* w) {
+    Fp r;
+#pragma unroll
+    for (int j = 0; j < FP_L; j++) {
+        int bit = 28 * j, wi = bit >> 5, sh = bit & 31;
+        u64 two = (u64)w[wi] | (wi + 1 < 12 ? (u64)w[wi + 1] << 32 : 0ull);
+        r.l[j] = (i32)((u32)(two >> sh) & FP_MASK);
+    }
+    return r;
+}
+PS_INL void fp_to_words12(u32* w, const Fp& a) {  // a canonical (limbs in [0, 2^28))
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = 0;
+#pragma unroll
+    for (int j = 0; j < FP_L; j++) {
+        int bit = 28 * j, wi = bit >> 5, sh = bit & 31;
+        u64 v = (u64)(u32)a.l[j] << sh;
+        w[wi] |= (u32)v;
+        if (wi + 1 < 12) w[wi + 1] |= (u32)(v >> 32);
+    }
+}
+// plain canonical value -> Montgomery form (canonical limbs), and back
+PS_INL Fp fp_to_mont(const Fp& plain) {
+    Fp r2;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r2.l[i] = fp_r2_28(i);
+    return fp_canon(f_mul(plain, r2));
+}
+PS_INL Fp fp_from_mont(const Fp& a) {
+    Fp one = fp_zero();
+    one.l[0] = 1;
+    return fp_canon(f_mul(a, one));
+}
+// 48 big-endian bytes <-> Montgomery Fp.  ok is cleared for a non-canonical encoding (>= p).
+PS_HD inline Fp fp_from_be48(const uint8_t* p, bool& ok) {
+    u32 w[12];
+    for (int i = 0; i < 12; i++) {
+        const uint8_t* q = p + 4 * (11 - i);
+        w[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    ok = ok && fe_is_canonical<FpParams>(w);
+    return fp_to_mont(fp_from_words12(w));
+}
+PS_HD inline void fp_to_be48(uint8_t* p, const Fp& a) {
+    u32 w[12];
+    fp_to_words12(w, fp_from_mont(a));
+    for (int i = 0; i < 12; i++) {
+        uint8_t* q = p + 4 * (11 - i);
+        q[0] = (uint8_t)(w[i] >> 24); q[1] = (uint8_t)(w[i] >> 16); q[2] = (uint8_t)(w[i] >> 8); q[3] = (uint8_t)w[i];
+    }
+}
+
+// a^(p-2); 0 -> 0.  Square-and-multiply over the bits of p - 2 (a loop, not unrolled).
+PS_HD inline Fp f_inv(const Fp& a) {
+    u32 e[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) e[i] = FpParams::mod(i);
+    e[0] -= 2;  // p is odd and its low word is > 2
+    Fp acc = fp_one();
+    Fp base = a;
+    for (int i = 0; i < 381; i++) {
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fp_mul_call(acc, base);
+        base = fp_mul_call(base, base);
+    }
+    return acc;
+}
+
+PS_INL Fp f_zero(const Fp*) { return fp_zero(); }
+PS_INL Fp f_one(const Fp*) { return fp_one(); }
+PS_INL Fp f_dbl(const Fp& a) { return f_add(a, a); }
+
 // ---------------------------------------------------------------------------------------
-// Fp2 = Fp[u]/(u^2 + 1)
+// Fp2 = Fp[u]/(u^2 + 1).  Multiplications go through the out-of-line Fp product; Karatsuba
+// sums are carry-save normalised first so every Fp product sees class <= 2 operands, and the
+// results are normalised back to class ~1.
 // ---------------------------------------------------------------------------------------
 struct Fp2 {
     Fp c0, c1;
 };
-
-// Uniform free-function interface so curve code can be written once for Fp and Fp2.
-PS_INL Fp f_zero(const Fp*) { return fe_zero<FpParams>(); }
-PS_INL Fp f_one(const Fp*) { return fe_one<FpParams>(); }
-PS_INL Fp f_add(const Fp& a, const Fp& b) { return fe_add<FpParams>(a, b); }
-PS_INL Fp f_sub(const Fp& a, const Fp& b) { return fe_sub<FpParams>(a, b); }
-PS_INL Fp f_neg(const Fp& a) { return fe_neg<FpParams>(a); }
-PS_INL Fp f_mul(const Fp& a, const Fp& b) { return fe_mul<FpParams>(a, b); }
-PS_INL Fp f_sqr(const Fp& a) { return fe_sqr<FpParams>(a); }
-PS_INL bool f_is_zero(const Fp& a) { return fe_is_zero<FpParams>(a); }
-PS_INL bool f_eq(const Fp& a, const Fp& b) { return fe_eq<FpParams>(a, b); }
-PS_HD inline Fp f_inv(const Fp& a) { return fe_inv<FpParams>(a); }
-
-PS_INL Fp2 f_zero(const Fp2*) { return Fp2{fe_zero<FpParams>(), fe_zero<FpParams>()}; }
-PS_INL Fp2 f_one(const Fp2*) { return Fp2{fe_one<FpParams>(), fe_zero<FpParams>()}; }
+PS_INL Fp2 f_zero(const Fp2*) { return Fp2{fp_zero(), fp_zero()}; }
+PS_INL Fp2 f_one(const Fp2*) { return Fp2{fp_one(), fp_zero()}; }
 PS_INL Fp2 f_add(const Fp2& a, const Fp2& b) { return Fp2{f_add(a.c0, b.c0), f_add(a.c1, b.c1)}; }
 PS_INL Fp2 f_sub(const Fp2& a, const Fp2& b) { return Fp2{f_sub(a.c0, b.c0), f_sub(a.c1, b.c1)}; }
 PS_INL Fp2 f_neg(const Fp2& a) { return Fp2{f_neg(a.c0), f_neg(a.c1)}; }
+PS_INL Fp2 f_dbl(const Fp2& a) { return f_add(a, a); }
+PS_INL Fp2 f_norm(const Fp2& a) { return Fp2{f_norm(a.c0), f_norm(a.c1)}; }
 PS_INL Fp2 f_mul(const Fp2& a, const Fp2& b) {
-    // Karatsuba: 3 Fp multiplications
-    Fp t0 = f_mul(a.c0, b.c0);
-    Fp t1 = f_mul(a.c1, b.c1);
-    Fp s = f_mul(f_add(a.c0, a.c1), f_add(b.c0, b.c1));
-    return Fp2{f_sub(t0, t1), f_sub(f_sub(s, t0), t1)};
+    Fp a0 = f_norm(a.c0), a1 = f_norm(a.c1), b0 = f_norm(b.c0), b1 = f_norm(b.c1);
+    Fp t0 = fp_mul_call(a0, b0);
+    Fp t1 = fp_mul_call(a1, b1);
+    Fp s = fp_mul_call(f_add(a0, a1), f_add(b0, b1));
+    return Fp2{f_norm(f_sub(t0, t1)), f_norm(f_sub(f_sub(s, t0), t1))};
 }
 PS_INL Fp2 f_sqr(const Fp2& a) {
-    // (a0+a1)(a0-a1) + 2 a0 a1 u : 2 Fp multiplications
-    Fp t = f_mul(f_add(a.c0, a.c1), f_sub(a.c0, a.c1));
-    Fp m = f_mul(a.c0, a.c1);
-    return Fp2{t, f_add(m, m)};
+    Fp a0 = f_norm(a.c0), a1 = f_norm(a.c1);
+    Fp t = fp_mul_call(f_add(a0, a1), f_sub(a0, a1));
+    Fp m = fp_mul_call(a0, a1);
+    return Fp2{t, f_norm(f_add(m, m))};
 }
-PS_INL bool f_is_zero(const Fp2& a) { return f_is_zero(a.c0) & f_is_zero(a.c1); }
-PS_INL bool f_eq(const Fp2& a, const Fp2& b) { return f_eq(a.c0, b.c0) & f_eq(a.c1, b.c1); }
+PS_INL bool f_is_zero(const Fp2& a) { return f_is_zero(a.c0) && f_is_zero(a.c1); }
+PS_INL bool f_eq(const Fp2& a, const Fp2& b) { return f_eq(a.c0, b.c0) && f_eq(a.c1, b.c1); }
 PS_HD inline Fp2 f_inv(const Fp2& a) {
-    Fp d = f_inv(f_add(f_sqr(a.c0), f_sqr(a.c1)));
-    return Fp2{f_mul(a.c0, d), f_neg(f_mul(a.c1, d))};
+    Fp a0 = f_norm(a.c0), a1 = f_norm(a.c1);
+    Fp d = f_inv(f_norm(f_add(fp_mul_call(a0, a0), fp_mul_call(a1, a1))));
+    return Fp2{fp_mul_call(a0, d), f_neg(fp_mul_call(a1, d))};
 }
+PS_INL bool fp_all_zero(const Fp2& a) { return fp_all_zero(a.c0) && fp_all_zero(a.c1); }
+PS_INL Fp2 fp_canon(const Fp2& a) { return Fp2{fp_canon(a.c0), fp_canon(a.c1)}; }
 
 }  // namespace ps

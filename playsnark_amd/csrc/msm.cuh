@@ -16,8 +16,8 @@
 //   6 k_reduce_*    per window  sum_b (b+1)*B[b]  by segment running sums + LDS tree
 //   host            Horner over the W window sums (c doublings each) and affine normalisation
 //
-// Data layout in HBM: points AoS affine Montgomery (96 B G1 / 192 B G2, 16-B aligned, read with
-// dwordx4 loads); scalars 8 x u32 little-endian plain; keys/ranks/sorted as [W][n] u32 so the
+// Data layout in HBM: points AoS affine Montgomery, 14 x 28-bit limbs per coordinate (112 B G1 /
+// 224 B G2, 16-B aligned, read with dwordx4 loads); scalars 8 x u32 little-endian plain; keys/ranks/sorted as [W][n] u32 so the
 // digit kernel's stores are coalesced across scalars; buckets and partials AoS XYZZ.
 #pragma once
 #include "curve.cuh"
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ keys, c
 // 4. bucket accumulation over fixed slices of the sorted entry list
 // ---------------------------------------------------------------------------------------
 template <class F>
-PS_INL bool affine_is_identity(const Affine<F>& p) { return f_is_zero(p.x) & f_is_zero(p.y); }
+PS_INL bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }  // stored points are canonical
 
 template <class F>
 __device__ inline void flush_run(const Xyzz<F>& acc, u32 g, u32 rs, u32 re, u32 slice_start, u32 t,
@@ -359,25 +359,9 @@ __global__ void __launch_bounds__(256) k_scalars_from_i64(const int64_t* __restr
     for (int j = 0; j < 8; j++) out[8 * (size_t)i + j] = a.l[j];
 }
 
-// raw big-endian coordinate (48 B) -> Montgomery Fp; ok=false if not canonical
-__device__ inline Fp fp_from_be48(const uint8_t* p, bool& ok) {
-    const u32* src = reinterpret_cast<const u32*>(p);
-    Fp a;
+PS_INL Fp curve_b(const Fp*) { Fp b; constexpr i32 v[FP_L] = PS_FP28_FOUR;
 #pragma unroll
-    for (int j = 0; j < 12; j++) a.l[j] = __builtin_bswap32(src[11 - j]);
-    ok = ok && fe_is_canonical<FpParams>(a.l);
-    return fe_to_mont<FpParams>(a);
-}
-__device__ inline void fp_to_be48(uint8_t* p, const Fp& a) {
-    Fp v = fe_from_mont<FpParams>(a);
-    u32* dst = reinterpret_cast<u32*>(p);
-#pragma unroll
-    for (int j = 0; j < 12; j++) dst[11 - j] = __builtin_bswap32(v.l[j]);
-}
-
-PS_INL Fp curve_b(const Fp*) { Fp b; constexpr u32 v[12] = PS_FP_FOUR;
-#pragma unroll
-    for (int i = 0; i < 12; i++) b.l[i] = v[i];
+    for (int i = 0; i < FP_L; i++) b.l[i] = v[i];
     return b; }
 PS_INL Fp2 curve_b(const Fp2*) { Fp b = curve_b((const Fp*)0); return Fp2{b, b}; }
 
@@ -396,7 +380,7 @@ __global__ void __launch_bounds__(256) k_points_from_bytes_g1(const uint8_t* __r
     const uint8_t* p = in + 96 * (size_t)i;
     Affine<Fp> a;
     if (p[0] & 0x40) {
-        a.x = fe_zero<FpParams>(); a.y = fe_zero<FpParams>();
+        a.x = fp_zero(); a.y = fp_zero();
     } else {
         bool ok = (p[0] & 0xE0) == 0;
         a.x = fp_from_be48(p, ok);
@@ -450,17 +434,17 @@ __global__ void __launch_bounds__(256) k_points_to_bytes_g2(const Affine<Fp2>* _
 
 PS_INL Affine<Fp> generator(const Fp*) {
     Affine<Fp> g;
-    constexpr u32 x[12] = PS_G1_GEN_X; constexpr u32 y[12] = PS_G1_GEN_Y;
+    constexpr i32 x[FP_L] = PS_G1_GEN28_X; constexpr i32 y[FP_L] = PS_G1_GEN28_Y;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { g.x.l[i] = x[i]; g.y.l[i] = y[i]; }
+    for (int i = 0; i < FP_L; i++) { g.x.l[i] = x[i]; g.y.l[i] = y[i]; }
     return g;
 }
 PS_INL Affine<Fp2> generator(const Fp2*) {
     Affine<Fp2> g;
-    constexpr u32 x0[12] = PS_G2_GEN_X0; constexpr u32 x1[12] = PS_G2_GEN_X1;
-    constexpr u32 y0[12] = PS_G2_GEN_Y0; constexpr u32 y1[12] = PS_G2_GEN_Y1;
+    constexpr i32 x0[FP_L] = PS_G2_GEN28_X0; constexpr i32 x1[FP_L] = PS_G2_GEN28_X1;
+    constexpr i32 y0[FP_L] = PS_G2_GEN28_Y0; constexpr i32 y1[FP_L] = PS_G2_GEN28_Y1;
 #pragma unroll
-    for (int i = 0; i < 12; i++) { g.x.c0.l[i] = x0[i]; g.x.c1.l[i] = x1[i]; g.y.c0.l[i] = y0[i]; g.y.c1.l[i] = y1[i]; }
+    for (int i = 0; i < FP_L; i++) { g.x.c0.l[i] = x0[i]; g.x.c1.l[i] = x1[i]; g.y.c0.l[i] = y0[i]; g.y.c1.l[i] = y1[i]; }
     return g;
 }
 

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/playsnark_hip.h declares; the
+product does not depend on the oracle; compute entry points fail loudly without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "playsnark_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from playsnark_amd import _lib
+
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in playsnark_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_product_does_not_touch_the_oracle():
+    """A product path that routes through the oracle voids every parity claim."""
+    pkg = os.path.join(ROOT, "playsnark_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".inc", ".h", ".cpp")) and f != "gen_constants.py":
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+    out = subprocess.run(["nm", "-D", os.path.join(pkg, "libplaysnark_hip.so")], capture_output=True, text=True).stdout
+    assert " or_" not in out
+    assert "ps_msm" in out
+
+
+def test_no_cpu_fallback_without_a_device():
+    from playsnark_amd import api
+
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.PlaysnarkError) as e:
+        api.Context(0)
+    assert e.value.code == -6
+
+
+def test_host_fold_of_partial_sums(co):
+    """ps_points_sum is host code of the product (folds the per-GPU partial sums)."""
+    from playsnark_amd import api
+
+    raw = co.G1.gen_points(11, 13, 7) + co.G1.to_b(None)
+    want = None
+    for p in co.G1.unpack(raw):
+        want = co.G1.add(want, p)
+    assert api.points_sum(api.G1, raw) == co.G1.to_b(want)
+    p = co.G1.unpack(raw)[0]
+    neg = (p[0], (-p[1]) % (2**381))  # not on the curve / not canonical -> rejected
+    with pytest.raises(api.PlaysnarkError):
+        api.points_sum(api.G1, co.G1.to_b(p)[:48] + (neg[1] | 1 << 380).to_bytes(48, "big"))

@@ -1,0 +1,45 @@
+"""CPU, world_size 2, gloo: the multi-GPU exchange of the sharded MSM.  Each rank
+owns an index-range shard, the per-rank partial sums are all_gathered and folded by the product's
+ps_points_sum.  Without a GPU the local MSM of each rank is supplied by the oracle; the sharding,
+the collective and the fold are the code under test."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from oracle import coracle as co, pyref as pr
+from playsnark_amd import api
+from playsnark_amd.dist import ShardedMsm, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 301
+rng = pr.SplitMix64(77)
+sc = [rng.fr() for _ in range(n)]
+for grp, gid in ((co.G1, api.G1), (co.G2, api.G2)):
+    raw = grp.gen_points(123, 457, n)
+    first, cnt = shard_range(n, rank, world)
+    partial = grp.to_b(grp.msm_pippenger(co.pack_fr(sc[first:first + cnt]), raw[first * grp.nb:(first + cnt) * grp.nb], cnt, 1))
+    total = ShardedMsm(None, gid, dist, world).combine(partial)
+    want = grp.to_b(grp.msm_pippenger(co.pack_fr(sc), raw, n, 2))
+    assert total == want, (rank, grp.name)
+covered = sorted(sum((list(range(*(lambda f, c: (f, f + c))(*shard_range(10, r, 3)))) for r in range(3)), []))
+assert covered == list(range(10))
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_msm_exchange_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2
