@@ -103,12 +103,16 @@ def lagrange_at(n: int, x: int):
     fact = [1] * (n + 1)
     for i in range(1, n + 1):
         fact[i] = fact[i - 1] * i % R
+    ifact = [1] * (n + 1)
+    ifact[n] = pr.fr_inv(fact[n])
+    for i in range(n, 0, -1):
+        ifact[i - 1] = ifact[i] * i % R
     out = []
     for j in range(1, n + 1):
-        den = fact[j - 1] * fact[n - j] % R
+        iden = ifact[j - 1] * ifact[n - j] % R  # 1 / ((j-1)! (n-j)!), sign (-1)^(n-j)
         if (n - j) & 1:
-            den = (-den) % R
-        out.append(pre[j - 1] * suf[j + 1] % R * pr.fr_inv(den) % R)
+            iden = R - iden
+        out.append(pre[j - 1] * suf[j + 1] % R * iden % R)
     return out, pre[n]  # basis values, z(x)
 
 

@@ -1,0 +1,168 @@
+// C++ host mirror of the reference's Go surface for the prover hot path, header-only over the C
+// ABI (include/playsnark_hip.h).  The reference is compiled code (Go) whose toolchain is absent
+// from the build image, so this is the host side "in the reference's shape": same names,
+// argument meaning and error behaviour as algebra.go / qap.go / groth16.go / pinochio.go.
+//
+//   playsnark::Poly::BlindEval(points)          algebra.go:348-359
+//   playsnark::Poly::Mul(p2)                    algebra.go:92-105
+//   playsnark::QAP::Quotient(sol)               qap.go:151-162   (throws Apocalypse)
+//   playsnark::Groth16Prove(tr, q, sol, r, s)   groth16.go:122-211
+//   playsnark::PHGR13Prove(ek, qap, solution)   pinochio.go:207-254
+//
+// The reference panics; here the same conditions throw LengthMismatch (message of
+// algebra.go:351) and Apocalypse ("apocalypse", qap.go:159).  No arithmetic in this file.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/playsnark_hip.h"
+
+namespace playsnark {
+
+struct LengthMismatch : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Apocalypse : std::runtime_error { Apocalypse() : std::runtime_error("apocalypse") {} };
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc) {
+    if (rc == PS_OK) return;
+    if (rc == PS_ERR_LENGTH) throw LengthMismatch(ps_last_error());
+    if (rc == PS_ERR_NOT_DIVISIBLE) throw Apocalypse();
+    throw Error(rc, ps_last_error());
+}
+
+using Bytes = std::vector<uint8_t>;
+using Scalar = std::array<uint8_t, 32>;  // Element: 32-byte big-endian
+
+class Context {
+  public:
+    explicit Context(int device = 0) { check(ps_ctx_create(device, &h_)); }
+    ~Context() { ps_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ps_ctx* get() const { return h_; }
+    void sync() { check(ps_ctx_sync(h_)); }
+
+  private:
+    ps_ctx* h_ = nullptr;
+};
+
+// []G1 / []G2 resident on the device (Groth16Setup.Xi, PHGR13EvalKey.vs, ...)
+class Points {
+  public:
+    Points(Context& c, int group, const Bytes& affine) : ctx_(&c) {
+        const size_t wb = group == PS_G1 ? 96 : 192;
+        check(ps_points_upload(c.get(), group, affine.data(), affine.size() / wb, PS_FMT_AFFINE, &h_));
+    }
+    ~Points() { ps_points_free(h_); }
+    Points(const Points&) = delete;
+    Points& operator=(const Points&) = delete;
+    const ps_points* get() const { return h_; }
+    size_t size() const { return ps_points_len(h_); }
+    int group() const { return ps_points_group(h_); }
+
+  private:
+    Context* ctx_;
+    ps_points* h_ = nullptr;
+};
+
+// type Poly []Element (algebra.go:89); also Vector via FromValues (Value.ToFieldElement, curve.go:17-19)
+class Poly {
+  public:
+    Poly(Context& c, const std::vector<Scalar>& coeffs) : ctx_(&c) {
+        check(ps_scalars_upload(c.get(), coeffs.empty() ? nullptr : coeffs[0].data(), coeffs.size(), &h_));
+    }
+    static Poly FromValues(Context& c, const std::vector<int64_t>& v) {
+        ps_scalars* h = nullptr;
+        check(ps_scalars_upload_i64(c.get(), v.data(), v.size(), &h));
+        return Poly(c, h);
+    }
+    Poly(Poly&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+    ~Poly() { ps_scalars_free(h_); }
+    Poly(const Poly&) = delete;
+    Poly& operator=(const Poly&) = delete;
+    const ps_scalars* get() const { return h_; }
+    size_t size() const { return ps_scalars_len(h_); }
+
+    // func (p Poly) BlindEval(zero Commit, blindedPoint []Commit) Commit
+    Bytes BlindEval(const Points& blindedPoint) const {
+        Bytes out(blindedPoint.group() == PS_G1 ? 96 : 192);
+        check(ps_msm(ctx_->get(), blindedPoint.get(), h_, out.data()));
+        return out;
+    }
+    // func (p Poly) Mul(p2 Poly) Poly
+    Poly Mul(const Poly& p2) const {
+        ps_scalars* h = nullptr;
+        check(ps_poly_mul(ctx_->get(), h_, p2.h_, &h));
+        return Poly(*ctx_, h);
+    }
+    std::vector<Scalar> Download() const {
+        std::vector<Scalar> out(size());
+        if (!out.empty()) check(ps_scalars_download(ctx_->get(), h_, 0, out.size(), out[0].data()));
+        return out;
+    }
+
+  private:
+    friend class QAP;
+    Poly(Context& c, ps_scalars* h) : ctx_(&c), h_(h) {}
+    Context* ctx_;
+    ps_scalars* h_ = nullptr;
+};
+
+// type QAP (qap.go:10-27) in sparse evaluation form on the reference's domain {1..n}
+class QAP {
+  public:
+    struct Csr {
+        std::vector<uint32_t> row_ptr, col;
+        std::vector<int64_t> val;
+    };
+    QAP(Context& c, size_t nbVars, size_t nbIO, const Csr& left, const Csr& right, const Csr& out) : ctx_(&c) {
+        ps_csr l{left.row_ptr.data(), left.col.data(), left.val.data()};
+        ps_csr r{right.row_ptr.data(), right.col.data(), right.val.data()};
+        ps_csr o{out.row_ptr.data(), out.col.data(), out.val.data()};
+        check(ps_qap_create(c.get(), left.row_ptr.size() - 1, nbVars, nbIO, &l, &r, &o, &h_));
+    }
+    ~QAP() { ps_qap_free(h_); }
+    QAP(const QAP&) = delete;
+    QAP& operator=(const QAP&) = delete;
+    const ps_qap* get() const { return h_; }
+    // func (q QAP) Quotient(sol Vector) Poly -- throws Apocalypse on a non-zero remainder
+    Poly Quotient(const Poly& sol) const {
+        ps_scalars* h = nullptr;
+        check(ps_qap_quotient(ctx_->get(), h_, sol.get(), nullptr, nullptr, nullptr, &h));
+        return Poly(*ctx_, h);
+    }
+
+  private:
+    Context* ctx_;
+    ps_qap* h_ = nullptr;
+};
+
+struct Groth16Proof {  // groth16.go:106-118
+    Scalar R, S;
+    std::array<uint8_t, 96> A;
+    std::array<uint8_t, 192> B;
+    std::array<uint8_t, 96> C;
+};
+
+// func Groth16Prove(tr Groth16Setup, q QAP, sol Vector) Groth16Proof; r, s drawn by the caller
+inline Groth16Proof Groth16Prove(Context& c, const ps_groth16_pk& tr, const QAP& q, const Poly& sol, const Scalar& r,
+                                 const Scalar& s) {
+    Groth16Proof p{r, s, {}, {}, {}};
+    check(ps_groth16_prove(c.get(), &tr, q.get(), sol.get(), r.data(), s.data(), p.A.data(), p.B.data(), p.C.data()));
+    return p;
+}
+
+// func PHGR13Prove(ek PHGR13EvalKey, qap QAP, solution Vector) PHGR13Proof
+inline ps_phgr13_proof PHGR13Prove(Context& c, const ps_phgr13_ek& ek, const QAP& qap, const Poly& solution) {
+    ps_phgr13_proof out;
+    check(ps_phgr13_prove(c.get(), &ek, qap.get(), solution.get(), &out));
+    return out;
+}
+
+}  // namespace playsnark
