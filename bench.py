@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=16)
     args = ap.parse_args()
@@ -110,10 +111,11 @@ def main():
     #   points  P_i = a_i * G from the device fixed-base kernel (a_i uniform, seeded per rank)
     #   scalars uniform in [0, r)
     a = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 1000 + rank).tobytes())
-    points = api.Points.from_scalars(ctx, api.G1, a)
+    gid = api.G1 if args.group == "g1" else api.G2
+    points = api.Points.from_scalars(ctx, gid, a)
     scalars = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 2000 + rank).tobytes())
     ctx.sync()
-    msm = ShardedMsm(ctx, api.G1, dist, world)
+    msm = ShardedMsm(ctx, gid, dist, world)
 
     def barrier():
         if dist is not None:
@@ -156,7 +158,7 @@ def main():
         W, c = info["windows"], info["window_bits"]
         adds = info["entries"] + 2 * info["buckets"] + c * (W - 1) + W
         line = {
-            "metric": "G1 scalar-muls/s (Pippenger MSM, 2^%d pts per GPU)" % args.log2n,
+            "metric": "%s scalar-muls/s (Pippenger MSM, 2^%d pts per GPU)" % (args.group.upper(), args.log2n),
             "value": value,
             "unit": "G1 scalar-muls/s",
             "n_gpus": world,

@@ -9,7 +9,8 @@ _CSRC = os.path.join(_PKG, "csrc")
 
 
 def library_path() -> str:
-    return os.path.join(_PKG, "libplaysnark_hip.so")
+    """PLAYSNARK_HIP_LIB selects an alternative build of the same library (A/B experiments)."""
+    return os.environ.get("PLAYSNARK_HIP_LIB") or os.path.join(_PKG, "libplaysnark_hip.so")
 
 
 def _stale() -> bool:

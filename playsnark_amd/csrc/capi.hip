@@ -455,8 +455,10 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     const u64 total = (u64)pl.W * n;  // upper bound on entries
     const u64 G = pl.G;
     const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
-    const u32 segs_per_win = pl.NB / (u32)pl.SEG;
+    const u32 segs_per_win = pl.NB >> RED_SEG_LOG;
     const u32 nseg_total = segs_per_win * (u32)pl.W;
+    const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
+    const u32 l2_jobs = (u32)pl.W * (u32)(red_bits + 1);
     const u32 scan_tiles = (u32)((G + SCAN_TILE - 1) / SCAN_TILE);
     int rc;
     if ((rc = c->counts.ensure(4 * G))) return rc;
@@ -467,7 +469,7 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
     if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
-    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (size_t)nseg_total))) return rc;
+    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
     if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W + 64 > c->h_pinned_cap) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = c->stream;
@@ -494,10 +496,17 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     hipLaunchKernelGGL(k_fixup<F>, dim3(nblocks(G)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p);
     PS_STAGE_MARK();  // 5: after fixup
-    hipLaunchKernelGGL(k_reduce_segments<F>, dim3(nblocks(nseg_total)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
-                       pl.NB, pl.SEG, nseg_total, (Xyzz<F>*)c->segs.p);
-    hipLaunchKernelGGL(k_reduce_windows<F>, dim3(pl.W), dim3(256), 256 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)c->segs.p,
-                       segs_per_win, (Xyzz<F>*)c->wins.p);
+    {
+        Xyzz<F>* accs = (Xyzz<F>*)c->segs.p;
+        Xyzz<F>* runs = accs + nseg_total;
+        Xyzz<F>* l2 = runs + nseg_total;
+        hipLaunchKernelGGL(k_reduce_l1<F>, dim3(nblocks(nseg_total)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
+                           nseg_total, accs, runs);
+        hipLaunchKernelGGL(k_reduce_l2<F>, dim3(l2_jobs), dim3(256), 256 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
+                           (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
+        hipLaunchKernelGGL(k_reduce_l3<F>, dim3(1), dim3(64), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
+                           (Xyzz<F>*)c->wins.p);
+    }
     PS_STAGE_MARK();  // 6: after reduction
 #undef PS_STAGE_MARK
     c->ev_valid = c->timing;

@@ -402,7 +402,9 @@ PS_INL Fp f_sqr(const Fp& a) { return f_mul(a, a); }  // the compiler folds the 
 
 // Out-of-line copy for code paths where ten inlined multiplications per group operation would
 // not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(PS_FP2_INLINE)
+PS_INL Fp fp_mul_call(const Fp& a, const Fp& b) { return f_mul(a, b); }
+#elif defined(__HIP_DEVICE_COMPILE__)
 __host__ __device__ __attribute__((noinline)) Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }
 #else
 PS_HD inline Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }

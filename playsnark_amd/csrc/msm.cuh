@@ -13,7 +13,8 @@
 //                   flushing whenever the bucket id changes.  Buckets that lie inside one slice
 //                   are final; runs cut by a slice boundary go to a head/tail partial slot.
 //   5 k_fixup       per bucket: add up the partial slots of the slices it spans
-//   6 k_reduce_*    per window  sum_b (b+1)*B[b]  by segment running sums + LDS tree
+//   6 k_reduce_l1/l2/l3  per window  sum_b (b+1)*B[b]: 8-bucket running sums, then parallel tree sums
+//                   per weight bit, then a short Horner (dependency depth ~16 + ~16 + ~2c instead of 100+)
 //   host            Horner over the W window sums (c doublings each) and affine normalisation
 //
 // Data layout in HBM: points AoS affine Montgomery, 14 x 28-bit limbs per coordinate (112 B G1 /
@@ -51,7 +52,7 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     best.NB = 1u << (best.c - 1);
     best.G = (u64)best.W * best.NB;
     best.M = 32;
-    best.SEG = best.NB >= 32 ? 32 : (int)best.NB;
+    best.SEG = 8;
     return best;
 }
 
@@ -270,41 +271,53 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, 
 // ---------------------------------------------------------------------------------------
 // 6. bucket reduction: window sum = sum_{b=0}^{NB-1} (b+1) * B[b]
 // ---------------------------------------------------------------------------------------
-// stage 1: thread (w, s) owns buckets [s*SEG, (s+1)*SEG): running sum from the top,
-//          seg = sum (b - s*SEG + 1) B[b] + (s*SEG) * sum B[b]
+// A point addition is ~14 dependent multiplications (tens of microseconds per lane), so this phase
+// is bound by the length of its dependency chains, not by work.  Three short levels:
+//   L1  one thread per segment of 8 buckets: running sums  acc_s = sum (b-8s+1) B[b],
+//       run_s = sum B[b]                                   (depth 16, W*NB/8 threads)
+//   L2  window sum = sum_s acc_s + 8 * sum_s s*run_s, and s*run_s is split by the bits of s:
+//       T_k = sum over {s : bit k of s} run_s.  One block per (window, job): job 0 sums the
+//       acc_s, job k+1 sums T_k -- plain tree sums (depth ~ 8 + log2 256)
+//   L3  one thread per window: Horner over the bits, 2^3 shift, + job 0 (depth ~ 2(c-4)+4)
+constexpr int RED_SEG_LOG = 3;
+constexpr int RED_SEG = 1 << RED_SEG_LOG;
+
 template <class F>
-__global__ void __launch_bounds__(256, 2) k_reduce_segments(const Xyzz<F>* __restrict__ buckets, u32 NB, int SEG,
-                                                            u32 nseg_total, Xyzz<F>* __restrict__ segs) {
+__global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<F>* __restrict__ buckets, u32 nseg_total,
+                                                      Xyzz<F>* __restrict__ accs, Xyzz<F>* __restrict__ runs) {
     u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= nseg_total) return;
-    u32 segs_per_win = NB / (u32)SEG;
-    u32 w = idx / segs_per_win, s = idx % segs_per_win;
-    const Xyzz<F>* B = buckets + (size_t)w * NB + (size_t)s * SEG;
+    const Xyzz<F>* B = buckets + (size_t)idx * RED_SEG;
     Xyzz<F> run = xyzz_identity<F>(), acc = xyzz_identity<F>();
-    for (int b = SEG - 1; b >= 0; b--) {
+    for (int b = RED_SEG - 1; b >= 0; b--) {
         Xyzz<F> v = B[b];
         xyzz_add<F>(run, v);
         xyzz_add<F>(acc, run);
     }
-    u32 off = s * (u32)SEG;
-    if (off) {
-        Xyzz<F> sh = xyzz_mul_small<F>(run, off);
-        xyzz_add<F>(acc, sh);
-    }
-    segs[idx] = acc;
+    accs[idx] = acc;
+    runs[idx] = run;
 }
 
-// stage 2: one block per window sums its segment values (serial stride + LDS tree)
 template <class F>
-__global__ void __launch_bounds__(256) k_reduce_windows(const Xyzz<F>* __restrict__ segs, u32 segs_per_win,
-                                                        Xyzz<F>* __restrict__ win_sums) {
+__global__ void __launch_bounds__(256) k_reduce_l2(const Xyzz<F>* __restrict__ accs, const Xyzz<F>* __restrict__ runs,
+                                                   u32 segs_per_win, int nbits, Xyzz<F>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Xyzz<F>* sm = reinterpret_cast<Xyzz<F>*>(smem_raw);
-    const u32 w = blockIdx.x;
+    const u32 w = blockIdx.x / (u32)(nbits + 1), job = blockIdx.x % (u32)(nbits + 1);
     Xyzz<F> acc = xyzz_identity<F>();
-    for (u32 s = threadIdx.x; s < segs_per_win; s += blockDim.x) {
-        Xyzz<F> v = segs[(size_t)w * segs_per_win + s];
-        xyzz_add<F>(acc, v);
+    if (job == 0) {
+        for (u32 s = threadIdx.x; s < segs_per_win; s += blockDim.x) {
+            Xyzz<F> v = accs[(size_t)w * segs_per_win + s];
+            xyzz_add<F>(acc, v);
+        }
+    } else {
+        const int k = (int)job - 1;  // enumerate the s with bit k set: insert a 1 at position k of t
+        const u32 low = (1u << k) - 1u;
+        for (u32 t = threadIdx.x; t < (segs_per_win >> 1); t += blockDim.x) {
+            u32 s = ((t & ~low) << 1) | (1u << k) | (t & low);
+            Xyzz<F> v = runs[(size_t)w * segs_per_win + s];
+            xyzz_add<F>(acc, v);
+        }
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
@@ -316,7 +329,23 @@ __global__ void __launch_bounds__(256) k_reduce_windows(const Xyzz<F>* __restric
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) win_sums[w] = sm[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+template <class F>
+__global__ void __launch_bounds__(64) k_reduce_l3(const Xyzz<F>* __restrict__ l2, int nbits, int W,
+                                                  Xyzz<F>* __restrict__ win_sums) {
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const Xyzz<F>* v = l2 + (size_t)w * (nbits + 1);
+    Xyzz<F> acc = xyzz_identity<F>();
+    for (int k = nbits - 1; k >= 0; k--) {
+        acc = xyzz_dbl<F>(acc);
+        xyzz_add<F>(acc, v[1 + k]);
+    }
+    for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<F>(acc);
+    xyzz_add<F>(acc, v[0]);
+    win_sums[w] = acc;
 }
 
 // ---------------------------------------------------------------------------------------
