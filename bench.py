@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=20, help="points per GPU = 2^log2n")
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=16)
@@ -106,6 +107,8 @@ def main():
     ctx = api.Context(local_rank)
     if args.window:
         ctx.set_window(args.window)
+    if args.slice:
+        ctx.set_slice(args.slice)
     n = 1 << args.log2n
     # synthetic inputs, resident in HBM before the timed region:
     #   points  P_i = a_i * G from the device fixed-base kernel (a_i uniform, seeded per rank)

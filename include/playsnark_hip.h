@@ -104,6 +104,7 @@ typedef struct {
 } ps_msm_info;
 int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
 int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic, else 4..20 */);
+int ps_msm_set_slice(ps_ctx* ctx, int entries /* sorted entries per accumulation thread; 0 = automatic */);
 /* Per-stage device time of the last MSM, measured with HIP events on the context's own stream
  * (the stream the kernels run on).  Stages: 0 digits (+counter/bucket memsets), 1 scan,
  * 2 scatter, 3 accumulate (the dominant kernel), 4 fix-up, 5 bucket reduction. */

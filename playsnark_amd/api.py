@@ -71,6 +71,9 @@ class Context:
     def set_window(self, bits: int):
         _check(lib.ps_msm_set_window(self._h, bits))
 
+    def set_slice(self, entries: int):
+        _check(lib.ps_msm_set_slice(self._h, entries))
+
     STAGES = ("digits", "scan", "scatter", "accumulate", "fixup", "reduce")
 
     def set_timing(self, enable: bool):

@@ -66,7 +66,7 @@ struct ps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // MSM workspace
-    DevBuf counts, offs, bsum, keys, ranks, sorted, buckets, parts, segs, wins;
+    DevBuf counts, offs, bsum, keys, ranks, sorted, buckets, parts, segs, wins, heavy;
     DevBuf staging;                  // byte staging for uploads / downloads
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -79,6 +79,7 @@ struct ps_ctx {
     MsmPlan pending_plan{};
     ps_msm_info last_info{};
     int forced_c = 0;
+    int forced_slice = 0;
     QuotientCache* qcache = nullptr;
     // optional per-stage timing (HIP events on `stream`, the stream the kernels run on)
     bool timing = false;
@@ -152,7 +153,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
-                      &c->segs, &c->wins, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+                      &c->segs, &c->wins, &c->heavy, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -471,12 +472,15 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
     if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
     if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
+    const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
+    if ((rc = c->heavy.ensure(4 * (max_heavy + 1)))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W + 64 > c->h_pinned_cap) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = c->stream;
     int evi = 0;
 #define PS_STAGE_MARK() do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[evi++], st)); } while (0)
     PS_STAGE_MARK();  // 0: start
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
+    HIP_TRY(hipMemsetAsync(c->heavy.p, 0, 4, st));
     HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     hipLaunchKernelGGL(k_digits, dim3(nblocks(n)), dim3(256), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB,
                        (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->ranks.p);
@@ -494,7 +498,10 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
                        (Xyzz<F>*)c->parts.p);
     PS_STAGE_MARK();  // 4: after accumulate
     hipLaunchKernelGGL(k_fixup<F>, dim3(nblocks(G)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
-                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p);
+                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (u32*)c->heavy.p, (u32*)c->heavy.p + 1);
+    hipLaunchKernelGGL(k_fixup_heavy<F>, dim3(256), dim3(256), 256 * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
+                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (const u32*)c->heavy.p,
+                       (const u32*)c->heavy.p + 1);
     PS_STAGE_MARK();  // 5: after fixup
     {
         Xyzz<F>* accs = (Xyzz<F>*)c->segs.p;
@@ -542,6 +549,7 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
         return PS_OK;
     }
     MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
+    if (c->forced_slice) pl.M = c->forced_slice;
     int rc = pts->group == PS_G1 ? msm_launch_t<Fp>(c, pts, sc, pl) : msm_launch_t<Fp2>(c, pts, sc, pl);
     if (rc) return rc;
     c->pending = true;
@@ -593,6 +601,11 @@ extern "C" int ps_msm_i64(ps_ctx* c, const ps_points* pts, const int64_t* v, siz
 extern "C" int ps_msm_last_info(ps_ctx* c, ps_msm_info* out) {
     if (!c || !out) return fail(PS_ERR_ARG, "NULL argument");
     *out = c->last_info;
+    return PS_OK;
+}
+extern "C" int ps_msm_set_slice(ps_ctx* c, int entries) {
+    if (!c || entries < 0 || entries > 4096) return fail(PS_ERR_ARG, "slice must be 0 (automatic) or 1..4096");
+    c->forced_slice = entries;
     return PS_OK;
 }
 extern "C" int ps_ctx_set_timing(ps_ctx* c, int enable) {

@@ -86,9 +86,30 @@ __global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars,
         carry = neg;
         if (neg) d = (1u << c) - d;
         u32 key = 0xffffffffu, rank = 0;
-        if (d) {
-            key = (u32)w * NB + d - 1u;
-            rank = atomicAdd(&counts[key], 1u) | (neg << 31);
+        if (d) key = (u32)w * NB + d - 1u;
+        // Skewed scalar vectors (witness values, repeated scalars, the carry-only top window) send
+        // most lanes of a wave to one bucket; a single address sustains only ~90 atomics/us.  The
+        // lanes that share the first active lane's key are served by one atomic of their count.
+        {
+            const bool act = d != 0;
+            const unsigned long long active = __ballot(act);
+            bool done = !act;
+            if (active) {
+                const int leader = __ffsll((long long)active) - 1;
+                const u32 lkey = __shfl(key, leader, 64);
+                const unsigned long long same = __ballot(act && key == lkey);
+                if (__popcll(same) > 1) {
+                    u32 base = 0;
+                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counts[lkey], (u32)__popcll(same));
+                    base = __shfl(base, leader, 64);
+                    if (act && key == lkey) {
+                        const unsigned long long below = same & ((1ull << (threadIdx.x & 63)) - 1ull);
+                        rank = (base + (u32)__popcll(below)) | (neg << 31);
+                        done = true;
+                    }
+                }
+            }
+            if (!done) rank = atomicAdd(&counts[key], 1u) | (neg << 31);
         }
         keys[(size_t)w * n + i] = key;
         ranks[(size_t)w * n + i] = rank;
@@ -249,15 +270,22 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<F>* __restri
 // ---------------------------------------------------------------------------------------
 // 5. fix-up of buckets cut by slice boundaries
 // ---------------------------------------------------------------------------------------
+constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to k_fixup_heavy
+
 template <class F>
 __global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, u32 G, int M,
-                                                  const Xyzz<F>* __restrict__ parts, Xyzz<F>* __restrict__ buckets) {
+                                                  const Xyzz<F>* __restrict__ parts, Xyzz<F>* __restrict__ buckets,
+                                                  u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
     u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     u32 lo = offs[g], hi = offs[g + 1];
     if (lo == hi) return;  // empty bucket: stays the identity from the memset
     u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
     if (t0 == t1) return;  // lay inside one slice: already final
+    if (t1 - t0 >= HEAVY_SPAN) {  // long chain: one workgroup per bucket instead of one thread
+        heavy_list[atomicAdd(heavy_count, 1u)] = g;
+        return;
+    }
     Xyzz<F> acc = xyzz_identity<F>();
     for (u32 t = t0; t <= t1; t++) {
         u32 slice_start = t * (u32)M;
@@ -266,6 +294,42 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, 
         xyzz_add<F>(acc, part);
     }
     buckets[g] = acc;
+}
+
+// Heavy buckets (skewed scalars): the partial slots of slices t0..t1 are summed by a whole
+// workgroup -- strided serial sums, then an LDS tree -- so the dependency chain is
+// (t1-t0)/256 + 8 additions instead of t1-t0.
+template <class F>
+__global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ offs, int M, const Xyzz<F>* __restrict__ parts,
+                                                     Xyzz<F>* __restrict__ buckets, const u32* __restrict__ heavy_count,
+                                                     const u32* __restrict__ heavy_list) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    Xyzz<F>* sm = reinterpret_cast<Xyzz<F>*>(smem_raw);
+    const u32 nheavy = *heavy_count;
+    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const u32 g = heavy_list[h];
+        const u32 lo = offs[g], hi = offs[g + 1];
+        const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
+        Xyzz<F> acc = xyzz_identity<F>();
+        for (u32 t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+            u32 slice_start = t * (u32)M;
+            u32 rs = lo > slice_start ? lo : slice_start;
+            Xyzz<F> part = parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)];
+            xyzz_add<F>(acc, part);
+        }
+        sm[threadIdx.x] = acc;
+        __syncthreads();
+        for (u32 stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
+            if (threadIdx.x < stride) {
+                Xyzz<F> a = sm[threadIdx.x], b = sm[threadIdx.x + stride];
+                xyzz_add<F>(a, b);
+                sm[threadIdx.x] = a;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) buckets[g] = sm[0];
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------
