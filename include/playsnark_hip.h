@@ -92,6 +92,9 @@ int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, siz
  * leaves the per-window sums on the device; ps_msm_finish() waits and folds them on the host. */
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);
+/* Host-side conversion of ONE point between PS_FMT_AFFINE and PS_FMT_COMPRESSED (what the shim
+ * needs to feed proof elements back to kyber's UnmarshalBinary).  Validates the encoding. */
+int ps_point_convert(int group, int in_fmt, int out_fmt, const uint8_t* in, uint8_t* out);
 /* Sum of k affine points (the per-GPU partial sums of a sharded MSM, after the RCCL gather). */
 int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* out);
 /* Tuning / introspection of the last MSM on this context. */

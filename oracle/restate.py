@@ -265,7 +265,13 @@ def phgr13_setup(c: SparseR1CS, s, av, aw, ay, rv, rw, beta, gamma):
     )
     t = Bag(beta=beta, s=s, gv=gv, gw=gw, gy=gy, ry=ry, rv=rv, rw=rw, av=av, aw=aw, ay=ay, gamma=gamma,
             u=u, v=v, w=w, zs=zs)
-    return Bag(EK=ek, t=t)
+    bgamma = gamma * beta % R
+    vk = Bag(  # PHGR13VerifKey, pinochio.go:64-91,140-160 (points as tuples for oracle.pairing)
+        g1=G1.mul(1), av=G2.mul(av), aw=G1.mul(aw), ay=G2.mul(ay), gamma=G2.mul(gamma),
+        bgamma=G1.mul(bgamma), bgamma2=G2.mul(bgamma), yts=_mulpt(G2, zs, g2y),
+        vs=[_mulpt(G1, e, gv) for e in u], ws=[_mulpt(G2, e, gw) for e in v], ys=[_mulpt(G1, e, gy) for e in w],
+    )
+    return Bag(EK=ek, VK=vk, t=t)
 
 
 def phgr13_prove(ek, c: SparseR1CS, sol_fr, fast=False):

@@ -25,7 +25,7 @@ SYMBOLS = [
     "ps_points_slice", "ps_points_free",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
-    "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_points_sum",
+    "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
     "ps_groth16_prove", "ps_phgr13_prove",
@@ -99,6 +99,7 @@ def _load():
     lib.ps_msm_launch.argtypes = [vp, vp, vp]
     lib.ps_msm_finish.argtypes = [vp, C.c_char_p]
     lib.ps_points_sum.argtypes = [i, C.c_char_p, sz, C.c_char_p]
+    lib.ps_point_convert.argtypes = [i, i, i, C.c_char_p, C.c_char_p]
     lib.ps_msm_last_info.argtypes = [vp, C.POINTER(MsmInfo)]
     lib.ps_msm_set_window.argtypes = [vp, i]
     lib.ps_ctx_set_timing.argtypes = [vp, i]

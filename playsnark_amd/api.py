@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import PS_G1, PS_G2, lib
 
 G1, G2 = PS_G1, PS_G2
+FMT_AFFINE, FMT_COMPRESSED = _lib.PS_FMT_AFFINE, _lib.PS_FMT_COMPRESSED
 _WIRE = {PS_G1: 96, PS_G2: 192}
 
 
@@ -235,6 +236,13 @@ def msm_launch(ctx: Context, points: Points, scalars: Poly):
 def msm_finish(ctx: Context, group: int) -> bytes:
     out = C.create_string_buffer(_WIRE[group])
     _check(lib.ps_msm_finish(ctx._h, out))
+    return out.raw
+
+
+def point_convert(group: int, raw: bytes, in_fmt: int, out_fmt: int) -> bytes:
+    """One point between the ZCash uncompressed and compressed forms (kyber MarshalBinary)."""
+    out = C.create_string_buffer(_WIRE[group] if out_fmt == _lib.PS_FMT_AFFINE else _WIRE[group] // 2)
+    _check(lib.ps_point_convert(group, in_fmt, out_fmt, raw, out))
     return out.raw
 
 

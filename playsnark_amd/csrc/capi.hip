@@ -285,10 +285,10 @@ static int points_alloc(ps_ctx* c, int group, size_t n, ps_points** out) {
 extern "C" int ps_points_upload(ps_ctx* c, int group, const uint8_t* pts, size_t n, int fmt, ps_points** out) {
     if (!c || !out || (n && !pts)) return fail(PS_ERR_ARG, "ps_points_upload: NULL argument");
     if (group != PS_G1 && group != PS_G2) return fail(PS_ERR_ARG, "ps_points_upload: bad group");
-    if (fmt != PS_FMT_AFFINE) return fail(PS_ERR_ARG, "ps_points_upload: only PS_FMT_AFFINE is implemented");
+    if (fmt != PS_FMT_AFFINE && fmt != PS_FMT_COMPRESSED) return fail(PS_ERR_ARG, "ps_points_upload: bad format");
     if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t wb = wire_bytes(group);
+    const size_t wb = fmt == PS_FMT_AFFINE ? wire_bytes(group) : wire_bytes(group) / 2;
     int rc = c->staging.ensure(wb * n + 32);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -296,7 +296,14 @@ extern "C" int ps_points_upload(ps_ctx* c, int group, const uint8_t* pts, size_t
     rc = points_alloc(c, group, n, out);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
-    if (n) {
+    if (n && fmt == PS_FMT_COMPRESSED) {  // GPU batch decompression: one Fp / Fp2 square root per point
+        if (group == PS_G1)
+            hipLaunchKernelGGL(k_points_decompress<Fp>, dim3(nblocks(n)), dim3(256), 0, c->stream,
+                               (const uint8_t*)c->staging.p, (u32)n, (u32)wb, (Affine<Fp>*)(*out)->st->p, c->d_flag);
+        else
+            hipLaunchKernelGGL(k_points_decompress<Fp2>, dim3(nblocks(n)), dim3(256), 0, c->stream,
+                               (const uint8_t*)c->staging.p, (u32)n, (u32)wb, (Affine<Fp2>*)(*out)->st->p, c->d_flag);
+    } else if (n) {
         if (group == PS_G1)
             hipLaunchKernelGGL(k_points_from_bytes_g1, dim3(nblocks(n)), dim3(256), 0, c->stream,
                                (const uint8_t*)c->staging.p, (u32)n, (Affine<Fp>*)(*out)->st->p, c->d_flag);
@@ -439,6 +446,27 @@ static int points_sum_t(const uint8_t* pts, size_t k, uint8_t* out, size_t wb) {
     }
     write_affine(out, acc);
     return PS_OK;
+}
+template <class F>
+static int point_convert_t(int in_fmt, int out_fmt, const uint8_t* in, uint8_t* out, size_t wb) {
+    Affine<F> a;
+    bool ok = in_fmt == PS_FMT_AFFINE ? read_affine(a, in) : decompress_point(a, in);
+    if (!ok) return fail(PS_ERR_ENCODING, "ps_point_convert: bad point encoding");
+    if (out_fmt == PS_FMT_COMPRESSED) {
+        compress_point(out, a);
+        return PS_OK;
+    }
+    if (affine_is_identity<F>(a)) { memset(out, 0, wb); out[0] = 0x40; return PS_OK; }
+    write_affine(out, xyzz_from_affine<F>(a.x, a.y));
+    return PS_OK;
+}
+extern "C" int ps_point_convert(int group, int in_fmt, int out_fmt, const uint8_t* in, uint8_t* out) {
+    if (!in || !out) return fail(PS_ERR_ARG, "ps_point_convert: NULL argument");
+    if ((in_fmt != PS_FMT_AFFINE && in_fmt != PS_FMT_COMPRESSED) || (out_fmt != PS_FMT_AFFINE && out_fmt != PS_FMT_COMPRESSED))
+        return fail(PS_ERR_ARG, "ps_point_convert: bad format");
+    if (group == PS_G1) return point_convert_t<Fp>(in_fmt, out_fmt, in, out, 96);
+    if (group == PS_G2) return point_convert_t<Fp2>(in_fmt, out_fmt, in, out, 192);
+    return fail(PS_ERR_ARG, "bad group");
 }
 extern "C" int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* out) {
     if ((k && !pts) || !out) return fail(PS_ERR_ARG, "ps_points_sum: NULL argument");

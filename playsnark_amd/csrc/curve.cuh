@@ -111,7 +111,7 @@ PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
     F ppp = f_mul(p, pp);
     F q = f_mul(acc.x, pp);
     F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), q), q));
-    F y3 = f_norm(f_sub(f_mul(r, f_sub(q, x3)), f_mul(acc.y, ppp)));
+    F y3 = f_norm(f_mul2sub(r, f_sub(q, x3), acc.y, ppp));  // classes 2*2 + 1*1
     acc.zz = f_mul(acc.zz, pp);
     acc.zzz = f_mul(acc.zzz, ppp);
     acc.x = x3;
@@ -141,7 +141,7 @@ PS_HD inline void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
     F ppp = f_mul(p, pp);
     F qq = f_mul(u1, pp);
     F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), qq), qq));
-    F y3 = f_norm(f_sub(f_mul(r, f_sub(qq, x3)), f_mul(s1, ppp)));
+    F y3 = f_norm(f_mul2sub(r, f_sub(qq, x3), s1, ppp));
     acc.zz = f_mul(f_mul(acc.zz, q.zz), pp);
     acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), ppp);
     acc.x = x3;

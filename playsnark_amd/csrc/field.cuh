@@ -400,6 +400,41 @@ PS_INL Fp f_mul(const Fp& a, const Fp& b) {
 }
 PS_INL Fp f_sqr(const Fp& a) { return f_mul(a, a); }  // the compiler folds the symmetric products
 
+// a*b - c*d with ONE Montgomery reduction (588 mads instead of 784): both products accumulate in
+// the same columns.  Needs class(a)*class(b) + class(c)*class(d) <= 8.
+PS_INL Fp f_mul2sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    Fp r;
+    i32 m[FP_L];
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < FP_L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (i64)a.l[i] * (i64)b.l[k - i];
+            acc -= (i64)c.l[i] * (i64)d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        m[k] = (i32)(((u32)acc * FP_INV28) & FP_MASK);
+        acc += (i64)m[k] * (i64)fp_mod28(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = FP_L; k < 2 * FP_L - 1; k++) {
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) {
+            acc += (i64)a.l[i] * (i64)b.l[k - i];
+            acc -= (i64)c.l[i] * (i64)d.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        r.l[k - FP_L] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    r.l[FP_L - 1] = (i32)acc;
+    return r;
+}
+
 // Out-of-line copy for code paths where ten inlined multiplications per group operation would
 // not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
 #if defined(PS_FP2_INLINE)
@@ -566,6 +601,7 @@ PS_INL Fp2 f_sqr(const Fp2& a) {
     Fp m = fp_mul_call(a0, a1);
     return Fp2{t, f_norm(f_add(m, m))};
 }
+PS_INL Fp2 f_mul2sub(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d) { return f_sub(f_mul(a, b), f_mul(c, d)); }
 PS_INL bool f_is_zero(const Fp2& a) { return f_is_zero(a.c0) && f_is_zero(a.c1); }
 PS_INL bool f_eq(const Fp2& a, const Fp2& b) { return f_eq(a.c0, b.c0) && f_eq(a.c1, b.c1); }
 PS_HD inline Fp2 f_inv(const Fp2& a) {
@@ -574,6 +610,83 @@ PS_HD inline Fp2 f_inv(const Fp2& a) {
     return Fp2{fp_mul_call(a0, d), f_neg(fp_mul_call(a1, d))};
 }
 PS_INL bool fp_all_zero(const Fp2& a) { return fp_all_zero(a.c0) && fp_all_zero(a.c1); }
+
+// ---- square roots and the ZCash "lexicographically larger" bit (point decompression) ----
+PS_HD constexpr i32 fp_half28(int i) { constexpr i32 v[FP_L] = PS_FP28_HALF; return v[i]; }
+// a^e for a plain exponent given as 12 little-endian words (loop, out-of-line products)
+PS_HD inline Fp fp_pow_words(const Fp& a, const u32* e, int nbits) {
+    Fp acc = fp_one();
+    Fp base = a;
+    for (int i = 0; i < nbits; i++) {
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fp_mul_call(acc, base);
+        base = fp_mul_call(base, base);
+    }
+    return acc;
+}
+PS_HD inline void fp_exp_words(u32* e, int delta, int shift) {  // e = (p + delta) >> shift
+    i64 c = delta;
+    for (int i = 0; i < 12; i++) {
+        i64 v = (i64)FpParams::mod(i) + c;
+        e[i] = (u32)v;
+        c = v >> 32;
+    }
+    for (int i = 0; i < 12; i++) e[i] = (e[i] >> shift) | ((i + 1 < 12 && shift) ? e[i + 1] << (32 - shift) : 0u);
+}
+// sqrt in Fp (p = 3 mod 4): a^((p+1)/4); ok=false when a is a non-residue
+PS_HD inline Fp fp_sqrt(const Fp& a, bool& ok) {
+    u32 e[12];
+    fp_exp_words(e, 1, 2);  // (p+1)/4
+    Fp s = fp_pow_words(a, e, 380);
+    ok = ok && f_is_zero(f_sub(fp_mul_call(s, s), a));
+    return s;
+}
+// canonical plain value > (p-1)/2 ?
+PS_HD inline bool fp_lex_larger(const Fp& a_mont) {
+    Fp v = fp_from_mont(a_mont);  // canonical plain limbs
+    bool gt = false, decided = false;
+    for (int i = FP_L - 1; i >= 0; i--) {
+        if (!decided && v.l[i] != fp_half28(i)) { gt = v.l[i] > fp_half28(i); decided = true; }
+    }
+    return gt;
+}
+PS_HD inline Fp2 fp2_pow_words(const Fp2& a, const u32* e, int nbits);
+PS_HD inline bool fp_lex_larger(const Fp2& a_mont) {
+    Fp c1 = fp_from_mont(a_mont.c1);
+    if (!fp_all_zero(c1)) return fp_lex_larger(a_mont.c1);
+    return fp_lex_larger(a_mont.c0);
+}
 PS_INL Fp2 fp_canon(const Fp2& a) { return Fp2{fp_canon(a.c0), fp_canon(a.c1)}; }
+PS_HD inline Fp2 fp2_pow_words(const Fp2& a, const u32* e, int nbits) {
+    Fp2 acc = f_one((const Fp2*)0);
+    Fp2 base = a;
+    for (int i = 0; i < nbits; i++) {
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = f_mul(acc, base);
+        base = f_sqr(base);
+    }
+    return acc;
+}
+// sqrt in Fp2 = Fp[u]/(u^2+1), p = 3 mod 4 (Adj & Rodriguez-Henriquez, alg. 9)
+PS_HD inline Fp2 fp_sqrt(const Fp2& a, bool& ok) {
+    if (f_is_zero(a)) return f_zero((const Fp2*)0);
+    u32 e[12];
+    fp_exp_words(e, -3, 2);  // (p-3)/4
+    Fp2 a1 = fp2_pow_words(a, e, 380);
+    Fp2 alpha = f_mul(f_mul(a1, a1), a);
+    Fp2 conj = Fp2{alpha.c0, f_neg(alpha.c1)};  // alpha^p (Frobenius)
+    Fp2 a0 = f_mul(conj, alpha);
+    Fp2 minus_one = f_neg(f_one((const Fp2*)0));
+    if (f_eq(a0, minus_one)) { ok = false; return a; }
+    Fp2 x0 = f_mul(a1, a);
+    Fp2 x;
+    if (f_eq(alpha, minus_one)) {
+        x = Fp2{f_neg(x0.c1), x0.c0};  // u * x0
+    } else {
+        fp_exp_words(e, -1, 1);  // (p-1)/2
+        Fp2 b = fp2_pow_words(f_add(f_one((const Fp2*)0), alpha), e, 381);
+        x = f_mul(b, x0);
+    }
+    ok = ok && f_eq(f_sqr(x), a);
+    return x;
+}
 
 }  // namespace ps

@@ -525,6 +525,78 @@ __global__ void __launch_bounds__(256) k_points_to_bytes_g2(const Affine<Fp2>* _
     if (affine_is_identity<Fp2>(a)) p[0] = 0x40;
 }
 
+// ---- ZCash compressed encodings (what kyber's MarshalBinary emits [upstream], pinochio.go:258-272) ----
+// 48 B (G1) / 96 B (G2): x big-endian (G2: c1 then c0), top bits 0x80 compressed, 0x40 infinity,
+// 0x20 "y is lexicographically larger".  Returns false for a malformed encoding.
+PS_HD inline bool decompress_point(Affine<Fp>& a, const uint8_t* p) {
+    if (!(p[0] & 0x80)) return false;
+    if (p[0] & 0x40) {
+        bool zero = (p[0] & 0x3f) == 0;
+        for (int i = 1; i < 48; i++) zero = zero && p[i] == 0;
+        a.x = fp_zero(); a.y = fp_zero();
+        return zero;
+    }
+    uint8_t xb[48];
+    for (int i = 0; i < 48; i++) xb[i] = p[i];
+    xb[0] &= 0x1f;
+    bool ok = true;
+    a.x = fp_from_be48(xb, ok);
+    Fp rhs = f_add(f_mul(f_sqr(a.x), a.x), curve_b((const Fp*)0));
+    Fp y = fp_sqrt(f_norm(rhs), ok);
+    if (!ok) return false;
+    y = fp_canon(y);
+    if (fp_lex_larger(y) != ((p[0] & 0x20) != 0)) y = fp_canon(f_neg(y));
+    a.y = y;
+    return true;
+}
+PS_HD inline bool decompress_point(Affine<Fp2>& a, const uint8_t* p) {
+    if (!(p[0] & 0x80)) return false;
+    if (p[0] & 0x40) {
+        bool zero = (p[0] & 0x3f) == 0;
+        for (int i = 1; i < 96; i++) zero = zero && p[i] == 0;
+        a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0);
+        return zero;
+    }
+    uint8_t xb[48];
+    for (int i = 0; i < 48; i++) xb[i] = p[i];
+    xb[0] &= 0x1f;
+    bool ok = true;
+    a.x.c1 = fp_from_be48(xb, ok);
+    a.x.c0 = fp_from_be48(p + 48, ok);
+    Fp2 rhs = f_norm(f_add(f_mul(f_sqr(a.x), a.x), curve_b((const Fp2*)0)));
+    Fp2 y = fp_sqrt(rhs, ok);
+    if (!ok) return false;
+    y = fp_canon(y);
+    if (fp_lex_larger(y) != ((p[0] & 0x20) != 0)) y = fp_canon(f_neg(y));
+    a.y = y;
+    return true;
+}
+// affine (canonical Montgomery coordinates) -> compressed bytes
+PS_HD inline void compress_point(uint8_t* out, const Affine<Fp>& a) {
+    if (fp_all_zero(a.x) && fp_all_zero(a.y)) { for (int i = 0; i < 48; i++) out[i] = 0; out[0] = 0xC0; return; }
+    fp_to_be48(out, a.x);
+    out[0] |= 0x80 | (fp_lex_larger(a.y) ? 0x20 : 0);
+}
+PS_HD inline void compress_point(uint8_t* out, const Affine<Fp2>& a) {
+    if (fp_all_zero(a.x) && fp_all_zero(a.y)) { for (int i = 0; i < 96; i++) out[i] = 0; out[0] = 0xC0; return; }
+    fp_to_be48(out, a.x.c1);
+    fp_to_be48(out + 48, a.x.c0);
+    out[0] |= 0x80 | (fp_lex_larger(a.y) ? 0x20 : 0);
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_points_decompress(const uint8_t* __restrict__ in, u32 n, u32 stride,
+                                                           Affine<F>* __restrict__ out, u32* __restrict__ nbad) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a;
+    if (!decompress_point(a, in + (size_t)stride * i)) {
+        atomicAdd(nbad, 1u);
+        a.x = f_zero((const F*)0); a.y = f_zero((const F*)0);
+    }
+    out[i] = a;
+}
+
 PS_INL Affine<Fp> generator(const Fp*) {
     Affine<Fp> g;
     constexpr i32 x[FP_L] = PS_G1_GEN28_X; constexpr i32 y[FP_L] = PS_G1_GEN28_Y;

@@ -63,3 +63,43 @@ def test_host_fold_of_partial_sums(co):
     neg = (p[0], (-p[1]) % (2**381))  # not on the curve / not canonical -> rejected
     with pytest.raises(api.PlaysnarkError):
         api.points_sum(api.G1, co.G1.to_b(p)[:48] + (neg[1] | 1 << 380).to_bytes(48, "big"))
+
+
+def test_point_convert_matches_zcash_encoding(co, pr):
+    """Host-side conversion between the uncompressed and compressed ZCash forms (the form kyber's
+    MarshalBinary emits, pinochio.go:258-272): against the oracle / the Python twin, G1 and G2,
+    identity, both signs of y, and malformed encodings."""
+    from playsnark_amd import api
+
+    rng = pr.SplitMix64(991)
+    for grp, gid, comp, decomp in ((co.G1, api.G1, pr.g1_compress, pr.g1_decompress),
+                                   (co.G2, api.G2, pr.g2_compress, pr.g2_decompress)):
+        pts = grp.unpack(grp.gen_points(rng.fr(), rng.fr(), 6)) + [None]
+        for p in pts:
+            for q in (p, None if p is None else (p[0], _neg(pr, p[1]))):
+                aff, cmp_ = grp.to_b(q), comp(q)
+                assert api.point_convert(gid, aff, api.FMT_AFFINE, api.FMT_COMPRESSED) == cmp_
+                assert api.point_convert(gid, cmp_, api.FMT_COMPRESSED, api.FMT_AFFINE) == aff
+                assert api.point_convert(gid, cmp_, api.FMT_COMPRESSED, api.FMT_COMPRESSED) == cmp_
+        assert api.point_convert(gid, comp(grp.mul(1)), api.FMT_COMPRESSED, api.FMT_AFFINE) == grp.to_b(grp.mul(1))
+        # malformed: compressed flag missing, x with no point on the curve
+        good = bytearray(comp(pts[0]))
+        bad = bytes([good[0] & 0x7F]) + bytes(good[1:])
+        with pytest.raises(api.PlaysnarkError):
+            api.point_convert(gid, bad, api.FMT_COMPRESSED, api.FMT_AFFINE)
+        found = False
+        for delta in range(1, 40):
+            cand = bytearray(good)
+            cand[-1] = (cand[-1] + delta) & 0xFF
+            try:
+                decomp(bytes(cand))
+            except ValueError:
+                with pytest.raises(api.PlaysnarkError):
+                    api.point_convert(gid, bytes(cand), api.FMT_COMPRESSED, api.FMT_AFFINE)
+                found = True
+                break
+        assert found
+
+
+def _neg(pr, y):
+    return (-y) % pr.P if isinstance(y, int) else ((-y[0]) % pr.P, (-y[1]) % pr.P)

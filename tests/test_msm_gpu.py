@@ -189,3 +189,24 @@ def test_points_sum_folds_partial_sums(ps_api, co, pr):
     for p in co.G2.unpack(raw2):
         want = co.G2.add(want, p)
     assert ps_api.points_sum(ps_api.G2, raw2) == co.G2.to_b(want)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_compressed_upload_decompresses_on_the_gpu(ps_api, ctx, co, pr, name):
+    """ps_points_upload(PS_FMT_COMPRESSED): the batch square-root kernel against the oracle's
+    decompression, including the identity and both y signs; a bad encoding is rejected."""
+    gid, og = _grp(ps_api, co, name)
+    comp = pr.g1_compress if name == "g1" else pr.g2_compress
+    rng = _rng(pr, 31)
+    pts = og.unpack(og.gen_points(rng.fr(), rng.fr(), 37)) + [None]
+    pts += [(p[0], (pr.P - p[1]) % pr.P) if name == "g1" else (p[0], ((-p[1][0]) % pr.P, (-p[1][1]) % pr.P)) for p in pts[:5]]
+    raw_c = b"".join(comp(p) for p in pts)
+    dev = ps_api.Points.upload(ctx, gid, raw_c, fmt=ps_api.FMT_COMPRESSED)
+    assert dev.download() == og.pack(pts)
+    sc = [rng.fr() for _ in pts]
+    assert ps_api.Poly.upload(ctx, sc).BlindEval(dev) == og.to_b(og.blind_eval(sc, og.pack(pts)))
+    bad = bytearray(raw_c)
+    bad[0] &= 0x7F  # compressed flag cleared
+    with pytest.raises(ps_api.PlaysnarkError) as e:
+        ps_api.Points.upload(ctx, gid, bytes(bad), fmt=ps_api.FMT_COMPRESSED)
+    assert e.value.code == -3

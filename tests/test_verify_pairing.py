@@ -1,0 +1,93 @@
+"""Groth16Verify / PHGR13Verify (groth16.go:214-233, pinochio.go:281-378) on a pure-Python pairing:
+TestGroth16Verify (groth16_test.go:22-30), TestPinocchioProofValidDivision's final Verify
+(pinocchio_test.go:195) and TestPinocchioInvalidProof (pinocchio_test.go:198-278), first for the
+oracle's proofs on the CPU, then (gpu-marked) for proofs made by the HIP path -- the latter is a
+check of the GPU result by mathematics alone."""
+import pytest
+
+SEED = 0x706C6179736E61726B & 0xFFFFFFFFFFFFFFFF
+
+
+def _groth16_material(pr, co, rs, circuit="toy"):
+    rng = pr.SplitMix64(SEED + 404)
+    c, sol = (rs.toy_circuit() if circuit == "toy" else rs.synthetic_circuit(circuit))
+    if circuit == "toy":
+        wit, sol = sol, [pr.fr(v) for v in sol]
+    else:
+        wit = None
+    tr = rs.groth16_setup(c, *[rng.fr() for _ in range(5)])
+    r, s = rng.fr(), rng.fr()
+    diff = c.nbVars - c.nbIO
+    trp = rs.Bag(Alpha=co.G1.from_b(tr.Alpha), Beta2=co.G2.from_b(tr.Beta2), IoLP=co.G1.unpack(tr.IoLP),
+                 Gamma=co.G2.from_b(tr.Gamma), Delta2=co.G2.from_b(tr.Delta2))
+    return c, wit, sol, tr, trp, r, s, diff
+
+
+def test_pairing_is_bilinear_and_nondegenerate(pr):
+    from oracle import pairing as pg
+
+    e = pg.pair(pr.G1.gen, pr.G2.gen)
+    assert e != pg._ONE and pg.f12_pow(e, pr.R) == pg._ONE
+    assert pg.pair(pr.G1.mul(6), pr.G2.mul(35)) == pg.f12_pow(e, 210)
+    assert pg.pair(None, pr.G2.gen) == pg._ONE
+
+
+def test_TestGroth16Verify_on_oracle_proof(co, pr):
+    from oracle import pairing as pg
+    from oracle import restate as rs
+
+    c, wit, sol, tr, trp, r, s, diff = _groth16_material(pr, co, rs)
+    pf = rs.groth16_prove(tr, c, sol, r, s)
+    A, B, Cc = co.G1.from_b(pf.A), co.G2.from_b(pf.B), co.G1.from_b(pf.C)
+    assert pg.groth16_verify(trp, A, B, Cc, sol[:diff])
+    assert not pg.groth16_verify(trp, A, B, pr.G1.add(Cc, pr.G1.gen), sol[:diff])
+    assert not pg.groth16_verify(trp, A, B, Cc, [sol[0], (sol[1] + 1) % pr.R, sol[2]])
+
+
+def test_TestPinocchio_verify_and_invalid_proofs_on_oracle_proof(co, pr):
+    from oracle import pairing as pg
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 505)
+    c, wit = rs.toy_circuit()
+    sol = [pr.fr(v) for v in wit]
+    st = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    pp = rs.phgr13_prove(st.EK, c, sol)
+    diff = c.nbVars - c.nbIO
+    tup = lambda: rs.Bag(**{f: (co.G2 if f == "wss" else co.G1).from_b(getattr(pp, f))
+                            for f in ("vss", "vass", "wss", "wass", "yss", "yass", "hs", "gz")})
+    assert pg.phgr13_verify(st.VK, diff, tup(), sol[:diff])
+    rnd = pr.G1.mul(rng.fr())
+    for field in ("yss", "vss", "hs", "gz"):  # pinocchio_test.go:243-262
+        bad = tup()
+        setattr(bad, field, rnd)
+        assert not pg.phgr13_verify(st.VK, diff, bad, sol[:diff]), field
+
+
+@pytest.mark.gpu
+def test_gpu_proofs_pass_the_reference_verifiers(ps_api, ctx, co, pr):
+    from oracle import pairing as pg
+    from oracle import restate as rs
+
+    up = lambda g, b: ps_api.Points.upload(ctx, g, b)
+    for circuit in ("toy", 21):
+        c, wit, sol, tr, trp, r, s, diff = _groth16_material(pr, co, rs, circuit)
+        q = ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+        dsol = ps_api.Poly.from_values(ctx, wit) if wit else ps_api.Poly.upload(ctx, sol)
+        pk = ps_api.Groth16Setup(tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2, up(ps_api.G1, tr.Xi),
+                                 up(ps_api.G2, tr.Xi2), up(ps_api.G1, tr.NioLP), up(ps_api.G1, tr.XiT))
+        proof = ps_api.Groth16Prove(pk, q, dsol, r, s)
+        assert pg.groth16_verify(trp, co.G1.from_b(proof.A), co.G2.from_b(proof.B), co.G1.from_b(proof.C), sol[:diff])
+        # the proof elements also survive the compressed wire form kyber uses
+        Ac = ps_api.point_convert(ps_api.G1, proof.A, ps_api.FMT_AFFINE, ps_api.FMT_COMPRESSED)
+        assert co.g1_decompress(Ac) == co.G1.from_b(proof.A)
+    rng = pr.SplitMix64(SEED + 606)
+    c, wit = rs.toy_circuit()
+    sol = [pr.fr(v) for v in wit]
+    st = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    ek = ps_api.PHGR13EvalKey(**{f: up(ps_api.G2 if f == "ws" else ps_api.G1, getattr(st.EK, f))
+                                 for f in ps_api.PHGR13EvalKey.FIELDS})
+    q = ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+    pp = ps_api.PHGR13Prove(ek, q, ps_api.Poly.from_values(ctx, wit))
+    tup = rs.Bag(**{f: (co.G2 if f == "wss" else co.G1).from_b(getattr(pp, f)) for f in ps_api.PHGR13Proof.FIELDS})
+    assert pg.phgr13_verify(st.VK, c.nbVars - c.nbIO, tup, sol[: c.nbVars - c.nbIO])
