@@ -480,6 +480,8 @@ extern "C" int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* o
 // ---------------------------------------------------------------------------------------
 template <class F>
 static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl) {
+    typedef typename KernelField<F>::type KF;      // Fp -> Fp, Fp2 -> lane-split Fp2s
+    constexpr unsigned LN = FieldTraits<KF>::LANES;  // lanes per logical thread
     const size_t n = sc->n;
     const u64 total = (u64)pl.W * n;  // upper bound on entries
     const u64 G = pl.G;
@@ -521,13 +523,13 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->ranks.p,
                        (const u32*)c->offs.p, (u32)n, total, (u32*)c->sorted.p);
     PS_STAGE_MARK();  // 3: after scatter
-    hipLaunchKernelGGL(k_accumulate<F>, dim3(nblocks(nthreads_acc)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
+    hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,
                        (Xyzz<F>*)c->parts.p);
     PS_STAGE_MARK();  // 4: after accumulate
-    hipLaunchKernelGGL(k_fixup<F>, dim3(nblocks(G)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
+    hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (u32*)c->heavy.p, (u32*)c->heavy.p + 1);
-    hipLaunchKernelGGL(k_fixup_heavy<F>, dim3(256), dim3(256), 256 * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
+    hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
                        (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (const u32*)c->heavy.p,
                        (const u32*)c->heavy.p + 1);
     PS_STAGE_MARK();  // 5: after fixup
@@ -535,11 +537,11 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
         Xyzz<F>* accs = (Xyzz<F>*)c->segs.p;
         Xyzz<F>* runs = accs + nseg_total;
         Xyzz<F>* l2 = runs + nseg_total;
-        hipLaunchKernelGGL(k_reduce_l1<F>, dim3(nblocks(nseg_total)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
+        hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
                            nseg_total, accs, runs);
-        hipLaunchKernelGGL(k_reduce_l2<F>, dim3(l2_jobs), dim3(256), 256 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
+        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
                            (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
-        hipLaunchKernelGGL(k_reduce_l3<F>, dim3(1), dim3(64), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
+        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3(1), dim3(128), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
                            (Xyzz<F>*)c->wins.p);
     }
     PS_STAGE_MARK();  // 6: after reduction

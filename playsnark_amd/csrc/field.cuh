@@ -435,6 +435,41 @@ PS_INL Fp f_mul2sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
     return r;
 }
 
+// a*b + c*d with one reduction (the complex product of the lane-split Fp2, below)
+PS_INL Fp f_mul2add(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+    Fp r;
+    i32 m[FP_L];
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < FP_L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (i64)a.l[i] * (i64)b.l[k - i];
+            acc += (i64)c.l[i] * (i64)d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        m[k] = (i32)(((u32)acc * FP_INV28) & FP_MASK);
+        acc += (i64)m[k] * (i64)fp_mod28(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = FP_L; k < 2 * FP_L - 1; k++) {
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) {
+            acc += (i64)a.l[i] * (i64)b.l[k - i];
+            acc += (i64)c.l[i] * (i64)d.l[k - i];
+        }
+#pragma unroll
+        for (int i = k - FP_L + 1; i < FP_L; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
+        r.l[k - FP_L] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    r.l[FP_L - 1] = (i32)acc;
+    return r;
+}
+
+
 // Out-of-line copy for code paths where ten inlined multiplications per group operation would
 // not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
 #if defined(PS_FP2_INLINE)
@@ -687,6 +722,76 @@ PS_HD inline Fp2 fp_sqrt(const Fp2& a, bool& ok) {
     }
     ok = ok && f_eq(f_sqr(x), a);
     return x;
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Fp2s: an Fp2 element SPLIT ACROSS A LANE PAIR (device kernels only).  Even lane holds c0, odd
+// lane c1; the partner's limbs come through DPP quad_perm [1,0,3,2] (a full-rate v_mov_dpp, no
+// LDS).  Per-lane register state is that of the G1 kernels, so the G2 bucket kernels inline
+// everything and spill nothing; the price is 2 x 588 mads per product instead of Karatsuba's
+// 3 x 392.  Control flow must be uniform inside a pair (every kernel guarantees it: both lanes
+// carry the same logical thread).
+// ---------------------------------------------------------------------------------------
+struct Fp2s {
+    Fp v;
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ inline int pair_lane() { return (int)(threadIdx.x & 1u); }
+__device__ inline i32 pair_swap(i32 x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); }
+#else  // host pass: never executed, present so that __device__ code parses
+PS_HD inline int pair_lane() { return 0; }
+PS_HD inline i32 pair_swap(i32 x) { return x; }
+#endif
+PS_INL Fp pair_swap(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = pair_swap(a.l[i]);
+    return r;
+}
+PS_INL Fp2s f_zero(const Fp2s*) { return Fp2s{fp_zero()}; }
+PS_INL Fp2s f_one(const Fp2s*) { return Fp2s{pair_lane() ? fp_zero() : fp_one()}; }
+PS_INL Fp2s f_add(const Fp2s& a, const Fp2s& b) { return Fp2s{f_add(a.v, b.v)}; }
+PS_INL Fp2s f_sub(const Fp2s& a, const Fp2s& b) { return Fp2s{f_sub(a.v, b.v)}; }
+PS_INL Fp2s f_neg(const Fp2s& a) { return Fp2s{f_neg(a.v)}; }
+PS_INL Fp2s f_dbl(const Fp2s& a) { return Fp2s{f_add(a.v, a.v)}; }
+PS_INL Fp2s f_norm(const Fp2s& a) { return Fp2s{f_norm(a.v)}; }
+PS_INL Fp2s fp_canon(const Fp2s& a) { return Fp2s{fp_canon(a.v)}; }
+// (a0 + a1 u)(b0 + b1 u): even lane a0 b0 - a1 b1, odd lane a0 b1 + a1 b0, as X1*Y1 + X2*Y2.
+// Needs class(a)*class(b) <= 4.
+PS_INL Fp2s f_mul(const Fp2s& a, const Fp2s& b) {
+    const bool odd = pair_lane() != 0;
+    Fp ao = pair_swap(a.v), bo = pair_swap(b.v);
+    Fp x1, x2;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) {
+        x1.l[i] = odd ? ao.l[i] : a.v.l[i];
+        x2.l[i] = odd ? a.v.l[i] : -ao.l[i];
+    }
+    return Fp2s{f_mul2add(x1, b.v, x2, bo)};
+}
+// (a0 + a1)(a0 - a1) on the even lane, 2 a0 a1 on the odd lane
+PS_INL Fp2s f_sqr(const Fp2s& a) {
+    const bool odd = pair_lane() != 0;
+    Fp me = f_norm(a.v);
+    Fp ot = pair_swap(me);
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) {
+        x.l[i] = odd ? 2 * me.l[i] : me.l[i] + ot.l[i];
+        y.l[i] = odd ? ot.l[i] : me.l[i] - ot.l[i];
+    }
+    return Fp2s{f_mul(x, y)};
+}
+PS_INL Fp2s f_mul2sub(const Fp2s& a, const Fp2s& b, const Fp2s& c, const Fp2s& d) { return f_sub(f_mul(a, b), f_mul(c, d)); }
+PS_INL bool f_is_zero(const Fp2s& a) {
+    i32 z = f_is_zero(a.v) ? 1 : 0;
+    return (z & pair_swap(z)) != 0;
+}
+PS_INL bool f_eq(const Fp2s& a, const Fp2s& b) { return f_is_zero(f_sub(a, b)); }
+PS_INL bool fp_all_zero(const Fp2s& a) {
+    i32 z = fp_all_zero(a.v) ? 1 : 0;
+    return (z & pair_swap(z)) != 0;
 }
 
 }  // namespace ps

@@ -214,28 +214,87 @@ __global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ keys, c
 }
 
 // ---------------------------------------------------------------------------------------
+// element access: the bucket kernels are written once over a *kernel field* KF and a storage
+// field.  Fp -> Fp (one lane per logical thread).  Fp2 storage -> Fp2s (two lanes per logical
+// thread, each lane loads / stores its own component of the same Fp2 records in HBM or LDS).
+// ---------------------------------------------------------------------------------------
+template <class KF> struct FieldTraits { typedef KF Store; static constexpr int LANES = 1; };
+template <> struct FieldTraits<Fp2s> { typedef Fp2 Store; static constexpr int LANES = 2; };
+template <class S> struct KernelField { typedef S type; };
+template <> struct KernelField<Fp2> { typedef Fp2s type; };
+
+__device__ inline Fp ld_f(const Fp* p, const Fp*) { return *p; }
+__device__ inline void st_f(Fp* p, const Fp& v) { *p = v; }
+__device__ inline Fp2s ld_f(const Fp2* p, const Fp2s*) { return Fp2s{pair_lane() ? p->c1 : p->c0}; }
+__device__ inline void st_f(Fp2* p, const Fp2s& v) { if (pair_lane()) p->c1 = v.v; else p->c0 = v.v; }
+
+template <class KF>
+__device__ inline Affine<KF> ld_affine(const Affine<typename FieldTraits<KF>::Store>* p) {
+    Affine<KF> r;
+    r.x = ld_f(&p->x, (const KF*)0);
+    r.y = ld_f(&p->y, (const KF*)0);
+    return r;
+}
+template <class KF>
+__device__ inline Xyzz<KF> ld_xyzz(const Xyzz<typename FieldTraits<KF>::Store>* p) {
+    Xyzz<KF> r;
+    r.x = ld_f(&p->x, (const KF*)0);
+    r.y = ld_f(&p->y, (const KF*)0);
+    r.zz = ld_f(&p->zz, (const KF*)0);
+    r.zzz = ld_f(&p->zzz, (const KF*)0);
+    return r;
+}
+template <class KF>
+__device__ inline void st_xyzz(Xyzz<typename FieldTraits<KF>::Store>* p, const Xyzz<KF>& v) {
+    st_f(&p->x, v.x);
+    st_f(&p->y, v.y);
+    st_f(&p->zz, v.zz);
+    st_f(&p->zzz, v.zzz);
+}
+template <class KF> __device__ inline u32 logical_tid() { return (blockIdx.x * blockDim.x + threadIdx.x) / FieldTraits<KF>::LANES; }
+template <class KF> __device__ inline u32 logical_local() { return threadIdx.x / FieldTraits<KF>::LANES; }
+template <class KF> __device__ inline u32 logical_block() { return blockDim.x / FieldTraits<KF>::LANES; }
+template <class KF> __device__ inline bool pair_leader() { return FieldTraits<KF>::LANES == 1 || pair_lane() == 0; }
+
+// LDS tree sum over the logical threads of a block; result in sm[0]
+template <class KF>
+__device__ inline void block_tree_sum(Xyzz<typename FieldTraits<KF>::Store>* sm, const Xyzz<KF>& mine) {
+    const u32 lt = logical_local<KF>();
+    st_xyzz<KF>(&sm[lt], mine);
+    __syncthreads();
+    for (u32 stride = logical_block<KF>() >> 1; stride > 0; stride >>= 1) {
+        if (lt < stride) {
+            Xyzz<KF> a = ld_xyzz<KF>(&sm[lt]), b = ld_xyzz<KF>(&sm[lt + stride]);
+            xyzz_add<KF>(a, b);
+            st_xyzz<KF>(&sm[lt], a);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 4. bucket accumulation over fixed slices of the sorted entry list
 // ---------------------------------------------------------------------------------------
 template <class F>
 PS_INL bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }  // stored points are canonical
 
-template <class F>
-__device__ inline void flush_run(const Xyzz<F>& acc, u32 g, u32 rs, u32 re, u32 slice_start, u32 t,
-                                 const u32* __restrict__ offs, Xyzz<F>* __restrict__ buckets,
-                                 Xyzz<F>* __restrict__ parts) {
+template <class KF>
+__device__ inline void flush_run(const Xyzz<KF>& acc, u32 g, u32 rs, u32 re, u32 slice_start, u32 t,
+                                 const u32* __restrict__ offs, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                 Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts) {
     bool whole = (rs == offs[g]) && (re == offs[g + 1]);
-    if (whole) buckets[g] = acc;
-    else if (rs == slice_start) parts[2 * (size_t)t] = acc;
-    else parts[2 * (size_t)t + 1] = acc;
+    if (whole) st_xyzz<KF>(&buckets[g], acc);
+    else if (rs == slice_start) st_xyzz<KF>(&parts[2 * (size_t)t], acc);
+    else st_xyzz<KF>(&parts[2 * (size_t)t + 1], acc);
 }
 
-template <class F>
-__global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<F>* __restrict__ points,
+template <class KF>
+__global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<typename FieldTraits<KF>::Store>* __restrict__ points,
                                                        const u32* __restrict__ sorted, const u32* __restrict__ offs,
-                                                       u32 G, int M, Xyzz<F>* __restrict__ buckets,
-                                                       Xyzz<F>* __restrict__ parts) {
+                                                       u32 G, int M, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts) {
     const u32 E = offs[G];
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 t = logical_tid<KF>();
     const u64 start64 = (u64)t * (u64)M;
     if (start64 >= E) return;
     const u32 start = (u32)start64;
@@ -249,22 +308,22 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<F>* __restri
     u32 g = lo;
     u32 bend = offs[g + 1];
     u32 run_start = start;
-    Xyzz<F> acc = xyzz_identity<F>();
+    Xyzz<KF> acc = xyzz_identity<KF>();
     for (u32 p = start; p < end; p++) {
         if (p >= bend) {
-            flush_run<F>(acc, g, run_start, p, start, t, offs, buckets, parts);
-            acc = xyzz_identity<F>();
+            flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
+            acc = xyzz_identity<KF>();
             run_start = p;
             do { g++; bend = offs[g + 1]; } while (bend <= p);
         }
         u32 e = sorted[p];
-        Affine<F> pt = points[e & 0x7fffffffu];
-        if (!affine_is_identity<F>(pt)) {
+        Affine<KF> pt = ld_affine<KF>(&points[e & 0x7fffffffu]);
+        if (!affine_is_identity<KF>(pt)) {
             if (e >> 31) pt.y = f_neg(pt.y);
-            xyzz_madd<F>(acc, pt.x, pt.y);
+            xyzz_madd<KF>(acc, pt.x, pt.y);
         }
     }
-    flush_run<F>(acc, g, run_start, end, start, t, offs, buckets, parts);
+    flush_run<KF>(acc, g, run_start, end, start, t, offs, buckets, parts);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -272,62 +331,56 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<F>* __restri
 // ---------------------------------------------------------------------------------------
 constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to k_fixup_heavy
 
-template <class F>
+template <class KF>
 __global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, u32 G, int M,
-                                                  const Xyzz<F>* __restrict__ parts, Xyzz<F>* __restrict__ buckets,
+                                                  const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
+                                                  Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
-    u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 g = logical_tid<KF>();
     if (g >= G) return;
     u32 lo = offs[g], hi = offs[g + 1];
     if (lo == hi) return;  // empty bucket: stays the identity from the memset
     u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
     if (t0 == t1) return;  // lay inside one slice: already final
     if (t1 - t0 >= HEAVY_SPAN) {  // long chain: one workgroup per bucket instead of one thread
-        heavy_list[atomicAdd(heavy_count, 1u)] = g;
+        if (pair_leader<KF>()) heavy_list[atomicAdd(heavy_count, 1u)] = g;
         return;
     }
-    Xyzz<F> acc = xyzz_identity<F>();
+    Xyzz<KF> acc = xyzz_identity<KF>();
     for (u32 t = t0; t <= t1; t++) {
         u32 slice_start = t * (u32)M;
         u32 rs = lo > slice_start ? lo : slice_start;
-        Xyzz<F> part = parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)];
-        xyzz_add<F>(acc, part);
+        Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
+        xyzz_add<KF>(acc, part);
     }
-    buckets[g] = acc;
+    st_xyzz<KF>(&buckets[g], acc);
 }
 
 // Heavy buckets (skewed scalars): the partial slots of slices t0..t1 are summed by a whole
 // workgroup -- strided serial sums, then an LDS tree -- so the dependency chain is
 // (t1-t0)/256 + 8 additions instead of t1-t0.
-template <class F>
-__global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ offs, int M, const Xyzz<F>* __restrict__ parts,
-                                                     Xyzz<F>* __restrict__ buckets, const u32* __restrict__ heavy_count,
-                                                     const u32* __restrict__ heavy_list) {
+template <class KF>
+__global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ offs, int M,
+                                                     const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
+                                                     Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                     const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Xyzz<F>* sm = reinterpret_cast<Xyzz<F>*>(smem_raw);
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
     const u32 nheavy = *heavy_count;
     for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const u32 g = heavy_list[h];
         const u32 lo = offs[g], hi = offs[g + 1];
         const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
-        Xyzz<F> acc = xyzz_identity<F>();
-        for (u32 t = t0 + threadIdx.x; t <= t1; t += blockDim.x) {
+        Xyzz<KF> acc = xyzz_identity<KF>();
+        for (u32 t = t0 + logical_local<KF>(); t <= t1; t += logical_block<KF>()) {
             u32 slice_start = t * (u32)M;
             u32 rs = lo > slice_start ? lo : slice_start;
-            Xyzz<F> part = parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)];
-            xyzz_add<F>(acc, part);
+            Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
+            xyzz_add<KF>(acc, part);
         }
-        sm[threadIdx.x] = acc;
-        __syncthreads();
-        for (u32 stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
-            if (threadIdx.x < stride) {
-                Xyzz<F> a = sm[threadIdx.x], b = sm[threadIdx.x + stride];
-                xyzz_add<F>(a, b);
-                sm[threadIdx.x] = a;
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) buckets[g] = sm[0];
+        block_tree_sum<KF>(sm, acc);
+        if (logical_local<KF>() == 0) st_xyzz<KF>(&buckets[g], ld_xyzz<KF>(&sm[0]));
         __syncthreads();
     }
 }
@@ -346,70 +399,66 @@ __global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ off
 constexpr int RED_SEG_LOG = 3;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
 
-template <class F>
-__global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<F>* __restrict__ buckets, u32 nseg_total,
-                                                      Xyzz<F>* __restrict__ accs, Xyzz<F>* __restrict__ runs) {
-    u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+template <class KF>
+__global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                      u32 nseg_total, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
+                                                      Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs) {
+    u32 idx = logical_tid<KF>();
     if (idx >= nseg_total) return;
-    const Xyzz<F>* B = buckets + (size_t)idx * RED_SEG;
-    Xyzz<F> run = xyzz_identity<F>(), acc = xyzz_identity<F>();
+    const Xyzz<typename FieldTraits<KF>::Store>* B = buckets + (size_t)idx * RED_SEG;
+    Xyzz<KF> run = xyzz_identity<KF>(), acc = xyzz_identity<KF>();
     for (int b = RED_SEG - 1; b >= 0; b--) {
-        Xyzz<F> v = B[b];
-        xyzz_add<F>(run, v);
-        xyzz_add<F>(acc, run);
+        Xyzz<KF> v = ld_xyzz<KF>(&B[b]);
+        xyzz_add<KF>(run, v);
+        xyzz_add<KF>(acc, run);
     }
-    accs[idx] = acc;
-    runs[idx] = run;
+    st_xyzz<KF>(&accs[idx], acc);
+    st_xyzz<KF>(&runs[idx], run);
 }
 
-template <class F>
-__global__ void __launch_bounds__(256) k_reduce_l2(const Xyzz<F>* __restrict__ accs, const Xyzz<F>* __restrict__ runs,
-                                                   u32 segs_per_win, int nbits, Xyzz<F>* __restrict__ out) {
+template <class KF>
+__global__ void __launch_bounds__(256) k_reduce_l2(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
+                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
+                                                   u32 segs_per_win, int nbits,
+                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    Xyzz<F>* sm = reinterpret_cast<Xyzz<F>*>(smem_raw);
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
     const u32 w = blockIdx.x / (u32)(nbits + 1), job = blockIdx.x % (u32)(nbits + 1);
-    Xyzz<F> acc = xyzz_identity<F>();
+    const u32 lt = logical_local<KF>(), lb = logical_block<KF>();
+    Xyzz<KF> acc = xyzz_identity<KF>();
     if (job == 0) {
-        for (u32 s = threadIdx.x; s < segs_per_win; s += blockDim.x) {
-            Xyzz<F> v = accs[(size_t)w * segs_per_win + s];
-            xyzz_add<F>(acc, v);
+        for (u32 s = lt; s < segs_per_win; s += lb) {
+            Xyzz<KF> v = ld_xyzz<KF>(&accs[(size_t)w * segs_per_win + s]);
+            xyzz_add<KF>(acc, v);
         }
     } else {
         const int k = (int)job - 1;  // enumerate the s with bit k set: insert a 1 at position k of t
         const u32 low = (1u << k) - 1u;
-        for (u32 t = threadIdx.x; t < (segs_per_win >> 1); t += blockDim.x) {
+        for (u32 t = lt; t < (segs_per_win >> 1); t += lb) {
             u32 s = ((t & ~low) << 1) | (1u << k) | (t & low);
-            Xyzz<F> v = runs[(size_t)w * segs_per_win + s];
-            xyzz_add<F>(acc, v);
+            Xyzz<KF> v = ld_xyzz<KF>(&runs[(size_t)w * segs_per_win + s]);
+            xyzz_add<KF>(acc, v);
         }
     }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (u32 stride = blockDim.x >> 1; stride > 0; stride >>= 1) {
-        if (threadIdx.x < stride) {
-            Xyzz<F> a = sm[threadIdx.x], b = sm[threadIdx.x + stride];
-            xyzz_add<F>(a, b);
-            sm[threadIdx.x] = a;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+    block_tree_sum<KF>(sm, acc);
+    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
 }
 
-template <class F>
-__global__ void __launch_bounds__(64) k_reduce_l3(const Xyzz<F>* __restrict__ l2, int nbits, int W,
-                                                  Xyzz<F>* __restrict__ win_sums) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
+template <class KF>
+__global__ void __launch_bounds__(128) k_reduce_l3(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ l2, int nbits, int W,
+                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ win_sums) {
+    int w = (int)logical_tid<KF>();
     if (w >= W) return;
-    const Xyzz<F>* v = l2 + (size_t)w * (nbits + 1);
-    Xyzz<F> acc = xyzz_identity<F>();
+    const Xyzz<typename FieldTraits<KF>::Store>* v = l2 + (size_t)w * (nbits + 1);
+    Xyzz<KF> acc = xyzz_identity<KF>();
     for (int k = nbits - 1; k >= 0; k--) {
-        acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, v[1 + k]);
+        acc = xyzz_dbl<KF>(acc);
+        xyzz_add<KF>(acc, ld_xyzz<KF>(&v[1 + k]));
     }
-    for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<F>(acc);
-    xyzz_add<F>(acc, v[0]);
-    win_sums[w] = acc;
+    for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<KF>(acc);
+    xyzz_add<KF>(acc, ld_xyzz<KF>(&v[0]));
+    st_xyzz<KF>(&win_sums[w], acc);
 }
 
 // ---------------------------------------------------------------------------------------
