@@ -81,6 +81,13 @@ struct ps_ctx {
     int forced_c = 0;
     int forced_slice = 0;
     QuotientCache* qcache = nullptr;
+    // Groth16 fused driver: secondary context (own stream + workspace) for the concurrent G2 MSM,
+    // and the concatenated CRS arrays of the last proving key
+    ps_ctx* aux = nullptr;
+    unsigned long long g16_key[4] = {0, 0, 0, 0};
+    uint8_t g16_fixed[96 * 3 + 192 * 2] = {0};
+    ps_points *g16_pa = nullptr, *g16_pb = nullptr, *g16_pc = nullptr;
+    hipEvent_t g16_ready = nullptr;
     // optional per-stage timing (HIP events on `stream`, the stream the kernels run on)
     bool timing = false;
     hipEvent_t ev[PS_MSM_STAGES + 1] = {};
@@ -98,12 +105,14 @@ static void storage_unref(Storage* s) {
     }
 }
 
+static unsigned long long g_points_uid = 0;
 struct ps_points {
     int group;
     size_t n;
     Storage* st;
     size_t first;  // element offset into the storage
     int device;
+    unsigned long long uid = ++g_points_uid;  // identity for caches of derived arrays
 };
 struct ps_scalars {
     size_t n;
@@ -156,6 +165,11 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
                       &c->segs, &c->wins, &c->heavy, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
+    if (c->g16_pa) ps_points_free(c->g16_pa);
+    if (c->g16_pb) ps_points_free(c->g16_pb);
+    if (c->g16_pc) ps_points_free(c->g16_pc);
+    if (c->g16_ready) (void)hipEventDestroy(c->g16_ready);
+    if (c->aux) ps_ctx_destroy(c->aux);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -539,7 +553,7 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
         Xyzz<F>* l2 = runs + nseg_total;
         hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
                            nseg_total, accs, runs);
-        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
+        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
                            (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
         hipLaunchKernelGGL(k_reduce_l3<KF>, dim3(1), dim3(128), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
                            (Xyzz<F>*)c->wins.p);

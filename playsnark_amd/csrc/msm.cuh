@@ -417,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<typename FieldT
 }
 
 template <class KF>
-__global__ void __launch_bounds__(256) k_reduce_l2(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
+__global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                    const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
                                                    u32 segs_per_win, int nbits,
                                                    Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {

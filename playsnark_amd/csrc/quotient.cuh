@@ -185,6 +185,15 @@ __global__ void __launch_bounds__(256) k_two_minus(Fr* __restrict__ t, u64 n) {
     if (i == 0) { Fr one = fr_one(); v = fr_add(v, fr_add(one, one)); }
     t[i] = v;
 }
+// out (plain limbs) = s*A + r*B, element-wise; A, B, s, r in Montgomery form
+__global__ void __launch_bounds__(256) k_fr_lincomb_plain(u32* __restrict__ out, const Fr* __restrict__ A, const Fr* __restrict__ B,
+                                                          Fr s, Fr r, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = fe_from_mont<FrParams>(fr_add(fr_mul(A[i], s), fr_mul(B[i], r)));
+#pragma unroll
+    for (int j = 0; j < 8; j++) out[8 * i + j] = v.l[j];
+}
 __global__ void __launch_bounds__(64) k_set_one(Fr* __restrict__ p, u64 idx) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = fr_one();
 }
