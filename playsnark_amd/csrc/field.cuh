@@ -8,7 +8,8 @@
 //      Montgomery R = 2^392.  Products accumulate in 64-bit columns with no carry handling
 //      (14 * 2^58 fits), add/sub are 14 independent v_add_u32, reduction is lazy.  One
 //      multiplication is 392 mads + ~110 cheap ops, fully inlined (no call ABI, no scratch).
-//   Fr (255 bit, NTT / scalars): saturated 8 x 32-bit limbs, CIOS Montgomery (R = 2^256).
+//   Fr (255 bit, the NTT / quotient field): the same unsaturated scheme with 10 limbs, R = 2^280
+//      (200 mads per product).  Scalars at the MSM boundary stay plain 8 x 32-bit words (FrSat).
 // All loops are fully unrolled with compile-time indices so elements live in VGPRs.
 //
 // This is product code: it replaces, for the hot path, the arithmetic the reference gets
@@ -52,7 +53,7 @@ struct Fe {
     static constexpr int N = P::N;
     u32 l[P::N];
 };
-typedef Fe<FrParams> Fr;
+typedef Fe<FrParams> FrSat;  // plain / saturated 8 x 32-bit scalars (MSM digit extraction, I/O)
 
 // ---------------------------------------------------------------------------------------
 // basic helpers
@@ -724,6 +725,189 @@ PS_HD inline Fp2 fp_sqrt(const Fp2& a, bool& ok) {
     return x;
 }
 
+
+// =======================================================================================
+// Fr: unsaturated 10 x 28-bit signed limbs, Montgomery R = 2^280 (same discipline as Fp)
+// =======================================================================================
+// f_mul contract: class(a)*class(b) <= 11, |A|*|B| <= 2^22 r^2; result limbs 0..8 in [0, 2^28),
+// value in (-r/8, 9r/8).  Stored vectors are kept at class ~1 (fr_norm) and |V| < ~64 r.
+struct Fr {
+    i32 l[10];
+};
+constexpr int FR_L = 10;
+constexpr u32 FR_INV28 = PS_FR28_INV;
+PS_HD constexpr i32 fr_mod28(int i) { constexpr i32 v[FR_L] = PS_FR28_MOD; return v[i]; }
+PS_HD constexpr i32 fr_r1_28(int i) { constexpr i32 v[FR_L] = PS_FR28_R1; return v[i]; }
+PS_HD constexpr i32 fr_r2_28(int i) { constexpr i32 v[FR_L] = PS_FR28_R2; return v[i]; }
+
+PS_INL Fr fr_zero() {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r.l[i] = 0;
+    return r;
+}
+PS_INL Fr fr_one() {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r.l[i] = fr_r1_28(i);
+    return r;
+}
+PS_INL Fr fr_add(const Fr& a, const Fr& b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+PS_INL Fr fr_sub(const Fr& a, const Fr& b) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+PS_INL Fr fr_neg(const Fr& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r.l[i] = -a.l[i];
+    return r;
+}
+PS_INL Fr fr_norm(const Fr& a) {  // one parallel carry-save step
+    Fr r;
+    r.l[0] = (i32)((u32)a.l[0] & FP_MASK);
+#pragma unroll
+    for (int i = 1; i < FR_L - 1; i++) r.l[i] = (i32)((u32)a.l[i] & FP_MASK) + (a.l[i - 1] >> 28);
+    r.l[FR_L - 1] = a.l[FR_L - 1] + (a.l[FR_L - 2] >> 28);
+    return r;
+}
+PS_INL Fr fr_propagate(const Fr& a) {
+    Fr r;
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < FR_L - 1; i++) {
+        i32 t = a.l[i] + c;
+        r.l[i] = (i32)((u32)t & FP_MASK);
+        c = t >> 28;
+    }
+    r.l[FR_L - 1] = a.l[FR_L - 1] + c;
+    return r;
+}
+PS_INL Fr fr_mul(const Fr& a, const Fr& b) {
+    Fr r;
+    i32 m[FR_L];
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < FR_L; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fr_mod28(k - i);
+        m[k] = (i32)(((u32)acc * FR_INV28) & FP_MASK);
+        acc += (i64)m[k] * (i64)fr_mod28(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = FR_L; k < 2 * FR_L - 1; k++) {
+#pragma unroll
+        for (int i = k - FR_L + 1; i < FR_L; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
+#pragma unroll
+        for (int i = k - FR_L + 1; i < FR_L; i++) acc += (i64)m[i] * (i64)fr_mod28(k - i);
+        r.l[k - FR_L] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    r.l[FR_L - 1] = (i32)acc;
+    return r;
+}
+// canonical representative in [0, r) for V in (-2r, 3r)
+PS_INL Fr fr_canon(const Fr& a) {
+    Fr t = fr_propagate(a);
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        bool negv = t.l[FR_L - 1] < 0;
+        Fr u;
+#pragma unroll
+        for (int i = 0; i < FR_L; i++) u.l[i] = t.l[i] + (negv ? fr_mod28(i) : 0);
+        t = fr_propagate(u);
+    }
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+        Fr u;
+#pragma unroll
+        for (int i = 0; i < FR_L; i++) u.l[i] = t.l[i] - fr_mod28(i);
+        u = fr_propagate(u);
+        bool ge = u.l[FR_L - 1] >= 0;
+#pragma unroll
+        for (int i = 0; i < FR_L; i++) t.l[i] = ge ? u.l[i] : t.l[i];
+    }
+    return t;
+}
+PS_INL Fr fr_reduce(const Fr& a) { return fr_mul(a, fr_one()); }  // same residue, value back in (-r/8, 9r/8)
+PS_HD inline bool fr_is_zero(const Fr& a) {  // V == 0 (mod r); filter on limb 0, exact path behind it
+    u32 o = 0;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) o |= (u32)a.l[i];
+    if (o == 0) return true;
+    constexpr u32 RINV_POS = ((1u << 28) - FR_INV28) & FP_MASK;  // r^-1 mod 2^28
+    u32 q = (((u32)a.l[0] & FP_MASK) * RINV_POS) & FP_MASK;
+    if (q > 4096u && q < (1u << 28) - 4096u) return false;  // |V| < 4096 r by the storage discipline
+    Fr t = fr_canon(fr_reduce(a));
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) d |= (u32)t.l[i];
+    return d == 0;
+}
+// plain 256-bit little-endian words <-> 28-bit limbs (plain, canonical)
+PS_INL Fr fr_from_words8(const u32* w) {
+    Fr r;
+#pragma unroll
+    for (int j = 0; j < FR_L; j++) {
+        int bit = 28 * j, wi = bit >> 5, sh = bit & 31;
+        u64 two = (u64)w[wi] | (wi + 1 < 8 ? (u64)w[wi + 1] << 32 : 0ull);
+        r.l[j] = (i32)((u32)(two >> sh) & FP_MASK);
+    }
+    return r;
+}
+PS_INL void fr_to_words8(u32* w, const Fr& a) {  // a canonical
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = 0;
+#pragma unroll
+    for (int j = 0; j < FR_L; j++) {
+        int bit = 28 * j, wi = bit >> 5, sh = bit & 31;
+        u64 v = (u64)(u32)a.l[j] << sh;
+        if (wi < 8) w[wi] |= (u32)v;
+        if (wi + 1 < 8) w[wi + 1] |= (u32)(v >> 32);
+    }
+}
+PS_INL Fr fr_to_mont(const Fr& plain) {  // plain canonical limbs -> Montgomery form
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) r2.l[i] = fr_r2_28(i);
+    return fr_mul(plain, r2);
+}
+PS_INL Fr fr_from_mont(const Fr& a) {  // -> canonical plain limbs
+    Fr one = fr_zero();
+    one.l[0] = 1;
+    return fr_canon(fr_mul(a, one));
+}
+PS_INL Fr fr_from_u64(u64 v) {
+    Fr a = fr_zero();
+    a.l[0] = (i32)(v & FP_MASK);
+    a.l[1] = (i32)((v >> 28) & FP_MASK);
+    a.l[2] = (i32)(v >> 56);
+    return fr_to_mont(a);
+}
+PS_HD inline Fr fr_inv(const Fr& a) {  // a^(r-2)
+    u32 e[8];
+    for (int i = 0; i < 8; i++) e[i] = FrParams::mod(i);
+    e[0] -= 2;  // low word of r is 1: borrow
+    // r = ...00000001: r - 2 = ...ffffffff with a borrow from word 1
+    e[0] = 0xffffffffu; e[1] = FrParams::mod(1) - 1u;
+    Fr acc = fr_one();
+    Fr base = fr_reduce(a);
+    for (int i = 0; i < 255; i++) {
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fr_mul(acc, base);
+        base = fr_mul(base, base);
+    }
+    return acc;
+}
 
 // ---------------------------------------------------------------------------------------
 // Fp2s: an Fp2 element SPLIT ACROSS A LANE PAIR (device kernels only).  Even lane holds c0, odd

@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) k_scalars_from_i64(const int64_t* __restr
     if (i >= n) return;
     int64_t v = in[i];
     u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
-    Fr a = fe_zero<FrParams>();
+    FrSat a = fe_zero<FrParams>();
     a.l[0] = (u32)mag;
     a.l[1] = (u32)(mag >> 32);
     if (v < 0) a = fe_neg<FrParams>(a);

@@ -3,27 +3,29 @@
 // schoolbook (algebra.go:92-105).  Here the NTT is only a *multiplication engine* -- the QAP
 // lives on the reference's integer domain {1..n} (qap.go:42-55), see quotient.cuh.
 //
-// Forward = Gentleman-Sande DIF (natural in, bit-reversed out); inverse = Cooley-Tukey DIT
-// (bit-reversed in, natural out).  Point-wise products happen in the bit-reversed domain, so no
-// permutation pass exists.  A transform of 2^p points is cut into ceil(p/8) passes; each pass
-// stages a tile of 2^k rows x COLS columns (<= 2048 Fr = 64 KB) in LDS, runs k butterfly
-// stages there, and touches HBM exactly once for reading and once for writing.  Batched
-// transforms (many blocks of 2^p points back to back) use the same kernel: butterflies never
-// cross a 2^p boundary.
+// Forward = Cooley-Tukey butterflies (a + w b, a - w b) on natural-order input, bit-reversed
+// output; inverse = Gentleman-Sande butterflies (a + b, (a - b) w^-1) on bit-reversed input,
+// natural output.  Point-wise products happen in the bit-reversed domain, so no permutation pass
+// exists.  Two properties matter on this machine:
+//   * all butterflies of a block share ONE twiddle (w = omega^bitrev(block)), so twiddle traffic
+//     is a broadcast, not a gather;
+//   * the forward transform only ever *adds* a product to a value, so with the lazy Fr
+//     representation (field.cuh) values grow by ~r per stage and need no reduction at all; the
+//     inverse doubles per stage and is brought back by the 2^-k scaling at the end of each pass.
+// A transform of 2^p points is cut into ceil(p/8) passes; each pass stages a tile of 2^k rows x
+// COLS columns (2048 Fr = 80 KB) in LDS, runs k butterfly stages there, and touches HBM exactly
+// once for reading and once for writing.  Batched transforms (many blocks of 2^p points back to
+// back) use the same kernel: butterflies never cross a 2^p boundary.
 #pragma once
+#include <algorithm>
+
 #include "field.cuh"
 
 namespace ps {
 
-PS_INL Fr fr_add(const Fr& a, const Fr& b) { return fe_add<FrParams>(a, b); }
-PS_INL Fr fr_sub(const Fr& a, const Fr& b) { return fe_sub<FrParams>(a, b); }
-PS_INL Fr fr_mul(const Fr& a, const Fr& b) { return fe_mul<FrParams>(a, b); }
-PS_INL Fr fr_zero() { return fe_zero<FrParams>(); }
-PS_INL Fr fr_one() { return fe_one<FrParams>(); }
-
-__device__ __constant__ u32 c_fr_roots[33][8] = PS_FR_ROOTS;
-__device__ __constant__ u32 c_fr_roots_inv[33][8] = PS_FR_ROOTS_INV;
-__device__ __constant__ u32 c_fr_inv2pow[33][8] = PS_FR_INV2POW;
+__device__ __constant__ i32 c_fr_roots[33][10] = PS_FR28_ROOTS;
+__device__ __constant__ i32 c_fr_roots_inv[33][10] = PS_FR28_ROOTS_INV;
+__device__ __constant__ i32 c_fr_inv2pow[33][10] = PS_FR28_INV2POW;
 
 // tw[i] = w^i, w the primitive 2^log_tab-th root (or its inverse), i < 2^(log_tab-1)
 __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int log_tab, int inverse) {
@@ -33,9 +35,9 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
     for (int k = 0; k < log_tab - 1; k++) {
         if ((i >> k) & 1) {
             Fr r;
-            const u32* src = inverse ? c_fr_roots_inv[log_tab - k] : c_fr_roots[log_tab - k];
+            const i32* src = inverse ? c_fr_roots_inv[log_tab - k] : c_fr_roots[log_tab - k];
 #pragma unroll
-            for (int j = 0; j < 8; j++) r.l[j] = src[j];
+            for (int j = 0; j < FR_L; j++) r.l[j] = src[j];
             acc = fr_mul(acc, r);
         }
     }
@@ -43,20 +45,21 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
 }
 
 constexpr int NTT_MAX_K = 8;        // butterfly stages per pass
-constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 64 KB of LDS per workgroup
+constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
 
-// One pass: k stages with half-distances D*2^m, m = 0..k-1 (descending m for the DIF forward,
-// ascending for the DIT inverse).  Column q = (hi, lo) with lo = q mod D; element (t, q) lives
-// at hi*D*2^k + t*D + lo.
+// One pass over transforms of 2^p points: k stages with half-distances D*2^m, m = k-1..0 for the
+// forward transform and 0..k-1 for the inverse.  Column q = (hi, lo) with lo = q mod D; element
+// (t, q) lives at hi*D*2^k + t*D + lo.
 template <bool INV>
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, int logD, int k, int logCols,
-                                                  const Fr* __restrict__ tw, int log_tab, int scale_log) {
+__global__ void __launch_bounds__(1024) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+                                                  const Fr* __restrict__ tw, int log_tab) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
     const u32 COLS = 1u << logCols, rows = 1u << k;
     const u32 tile_elems = rows << logCols;
     const u64 q0 = (u64)blockIdx.x << logCols;
     const u64 Dm1 = (1ull << logD) - 1;
+    const u64 smask = (1ull << p) - 1;
     for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
         u32 t, col;
         if (logD >= logCols) { t = e >> logCols; col = e & (COLS - 1); }
@@ -70,28 +73,37 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, int log
     for (int st = 0; st < k; st++) {
         const int m = INV ? st : (k - 1 - st);
         const u32 mmask = (1u << m) - 1;
+        const int logh = logD + m;          // half-distance 2^logh
+        const int M = p - 1 - logh;         // this stage has 2^M blocks per transform
         for (u32 bf = threadIdx.x; bf < nbf; bf += blockDim.x) {
             u32 col = bf & (COLS - 1), r = bf >> logCols;
             u32 t0 = ((r >> m) << (m + 1)) | (r & mmask), t1 = t0 | (1u << m);
-            u64 lo = (q0 + col) & Dm1;
-            u64 j = ((u64)(t0 & mmask) << logD) + lo;
-            Fr w = tw[j << (log_tab - 1 - (logD + m))];
+            u64 q = q0 + col;
+            u64 i0 = ((q >> logD) << (logD + k)) + ((u64)t0 << logD) + (q & Dm1);
+            u32 blk = (u32)((i0 & smask) >> (logh + 1));
             Fr a = tile[t0 * COLS + col], b = tile[t1 * COLS + col];
-            if (!INV) {
-                tile[t0 * COLS + col] = fr_add(a, b);
-                tile[t1 * COLS + col] = fr_mul(fr_sub(a, b), w);
-            } else {
-                Fr bw = fr_mul(b, w);
-                tile[t0 * COLS + col] = fr_add(a, bw);
-                tile[t1 * COLS + col] = fr_sub(a, bw);
+            if (M > 0) {
+                u32 widx = (__brev(blk) >> (32 - M)) << (log_tab - 1 - M);
+                Fr w = tw[widx];
+                if (!INV) {
+                    Fr wb = fr_mul(b, w);
+                    tile[t0 * COLS + col] = fr_norm(fr_add(a, wb));
+                    tile[t1 * COLS + col] = fr_norm(fr_sub(a, wb));
+                } else {
+                    tile[t0 * COLS + col] = fr_norm(fr_add(a, b));
+                    tile[t1 * COLS + col] = fr_mul(fr_norm(fr_sub(a, b)), w);
+                }
+            } else {  // the single block of the outermost stage: w = 1
+                tile[t0 * COLS + col] = fr_norm(fr_add(a, b));
+                tile[t1 * COLS + col] = fr_norm(fr_sub(a, b));
             }
         }
         __syncthreads();
     }
     Fr sc;
-    if (scale_log >= 0) {
+    if (INV) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) sc.l[j] = c_fr_inv2pow[scale_log][j];
+        for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[k][j];
     }
     for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
         u32 t, col;
@@ -100,7 +112,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ data, int log
         u64 q = q0 + col;
         u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
         Fr v = tile[t * COLS + col];
-        if (scale_log >= 0) v = fr_mul(v, sc);
+        if (INV) v = fr_mul(v, sc);  // 2^-k of this pass; also pulls the doubled values back under ~r
         data[addr] = v;
     }
 }
@@ -141,7 +153,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     if (p > tb.log_tab) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
     int npass = (p + NTT_MAX_K - 1) / NTT_MAX_K;
-    // stage groups of nearly equal size; DIF walks them from the top, DIT from the bottom
+    // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
     int done = 0;
     for (int ps_i = 0; ps_i < npass; ps_i++) {
         int k = (p - done + (npass - ps_i) - 1) / (npass - ps_i);
@@ -152,9 +164,10 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         u64 cols_total = total >> k;
         unsigned grid = (unsigned)(cols_total >> logCols);
         size_t smem = ((size_t)sizeof(Fr) << k) << logCols;
-        int scale_log = (INV && ps_i == npass - 1) ? p : -1;
-        hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(256), smem, st, data, logD, k, logCols,
-                           INV ? tb.inv : tb.fwd, tb.log_tab, scale_log);
+        // one butterfly per thread and stage: 4 waves per SIMD hide the LDS and multiplier latency
+        unsigned threads = (unsigned)std::min<u64>(1024, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 1));
+        hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
+                           INV ? tb.inv : tb.fwd, tb.log_tab);
         done += k;
     }
     return hipGetLastError();
@@ -174,21 +187,22 @@ __global__ void __launch_bounds__(256) k_fr_copy_pad(Fr* __restrict__ dst, const
     if (i >= n_dst) return;
     dst[i] = i < n_src ? src[i] : fr_zero();
 }
-// plain little-endian limbs <-> Montgomery form
+// plain little-endian words (8 x u32, canonical) <-> Montgomery Fr
 __global__ void __launch_bounds__(256) k_fr_to_mont(Fr* __restrict__ dst, const u32* __restrict__ src, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr a;
+    u32 w[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) a.l[j] = src[8 * i + j];
-    dst[i] = fe_to_mont<FrParams>(a);
+    for (int j = 0; j < 8; j++) w[j] = src[8 * i + j];
+    dst[i] = fr_to_mont(fr_from_words8(w));
 }
 __global__ void __launch_bounds__(256) k_fr_from_mont(u32* __restrict__ dst, const Fr* __restrict__ src, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr a = fe_from_mont<FrParams>(src[i]);
+    u32 w[8];
+    fr_to_words8(w, fr_from_mont(src[i]));
 #pragma unroll
-    for (int j = 0; j < 8; j++) dst[8 * i + j] = a.l[j];
+    for (int j = 0; j < 8; j++) dst[8 * i + j] = w[j];
 }
 
 static inline unsigned nblk(u64 n) { return (unsigned)((n + 255) / 256); }

@@ -41,23 +41,17 @@ __device__ inline Fr fr_shfl_up1(const Fr& v) {  // lane l gets lane l-1's value
     Fr r;
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        u32 t = __shfl_up(v.l[j], 1, 64);
-        r.l[j] = lane == 0 ? 0u : t;
+    for (int j = 0; j < FR_L; j++) {
+        i32 t = __shfl_up(v.l[j], 1, 64);
+        r.l[j] = lane == 0 ? 0 : t;
     }
     return r;
 }
 __device__ inline Fr fr_shfl(const Fr& v, int src) {
     Fr r;
 #pragma unroll
-    for (int j = 0; j < 8; j++) r.l[j] = __shfl(v.l[j], src, 64);
+    for (int j = 0; j < FR_L; j++) r.l[j] = __shfl(v.l[j], src, 64);
     return r;
-}
-__device__ inline Fr fr_from_u64(u64 v) {
-    Fr a = fr_zero();
-    a.l[0] = (u32)v;
-    a.l[1] = (u32)(v >> 32);
-    return fe_to_mont<FrParams>(a);
 }
 
 // block b: N(x) = sum_{k=0..63} d[64b+k] * prod_{i=64b+1}^{64b+k} (x - i), in place.
@@ -76,7 +70,8 @@ __global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nbl
         Fr dk = fr_shfl(mine, k);
         coef = fr_sub(up, fr_mul(c, coef));
         if (lane == 0) coef = fr_add(coef, dk);
-        c = fr_sub(c, one);
+        coef = fr_norm(coef);  // lazy: values grow by ~r per step (<= 70 r), limbs stay at class ~1
+        c = fr_norm(fr_sub(c, one));
     }
     d[base + lane] = coef;
 }
@@ -92,8 +87,8 @@ __global__ void __launch_bounds__(256) k_subproduct_base(Fr* __restrict__ out, u
     const Fr one = fr_one();
     for (int k = 0; k < 64; k++) {
         Fr up = fr_shfl_up1(coef);
-        coef = fr_sub(up, fr_mul(c, coef));
-        c = fr_add(c, one);
+        coef = fr_norm(fr_sub(up, fr_mul(c, coef)));
+        c = fr_norm(fr_add(c, one));
     }
     out[base + lane] = coef;
 }
@@ -116,7 +111,7 @@ __global__ void __launch_bounds__(256) k_level_combine(Fr* __restrict__ data, co
     u64 half = 1ull << (logs - 1);
     u64 i = idx & ((1ull << logs) - 1);
     Fr s = scratch[idx];
-    data[idx] = i < half ? fr_add(data[idx], s) : s;
+    data[idx] = i < half ? fr_norm(fr_add(data[idx], s)) : s;
 }
 // full[node*2t + i] = i < t ? F[node*t + i] : (i == t ? 1 : 0)
 __global__ void __launch_bounds__(256) k_tree_expand(Fr* __restrict__ full, const Fr* __restrict__ F, u64 total2, int logt) {
@@ -137,7 +132,7 @@ __global__ void __launch_bounds__(256) k_tree_pair_mul(Fr* __restrict__ prod, co
 __global__ void __launch_bounds__(256) k_tree_fix(Fr* __restrict__ F2, u64 nodes, int log2t) {
     u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nodes) return;
-    F2[p << log2t] = fr_sub(F2[p << log2t], fr_one());
+    F2[p << log2t] = fr_norm(fr_sub(F2[p << log2t], fr_one()));
 }
 // zhat[p*2t + i] = full[(2p)*2t + i]  (left children only)
 __global__ void __launch_bounds__(256) k_tree_take_left(Fr* __restrict__ zhat, const Fr* __restrict__ full, u64 total, int log2t) {
@@ -155,14 +150,17 @@ __global__ void __launch_bounds__(256) k_spmv(const u32* __restrict__ row_ptr, c
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     Fr acc = fr_zero();
-    for (u32 e = row_ptr[r]; e < row_ptr[r + 1]; e++) acc = fr_add(acc, fr_mul(val[e], x[col[e]]));
+    for (u32 e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        acc = fr_norm(fr_add(acc, fr_mul(val[e], x[col[e]])));
+        if (((e - row_ptr[r]) & 31u) == 31u) acc = fr_reduce(acc);  // dense rows: keep |value| small
+    }
     y[r] = acc;
 }
 __global__ void __launch_bounds__(256) k_check_gates(const Fr* __restrict__ yA, const Fr* __restrict__ yB,
                                                      const Fr* __restrict__ yC, u32 n, u32* __restrict__ flag) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    if (!fe_eq<FrParams>(fr_mul(yA[r], yB[r]), yC[r])) atomicOr(flag, 1u);
+    if (!fr_is_zero(fr_sub(fr_mul(yA[r], yB[r]), yC[r]))) atomicOr(flag, 1u);
 }
 // out[j] = j < n ? y[j] * invfact[j] : 0   for j < total
 __global__ void __launch_bounds__(256) k_scale_pad(Fr* __restrict__ out, const Fr* __restrict__ y, const Fr* __restrict__ invfact,
@@ -181,18 +179,19 @@ __global__ void __launch_bounds__(256) k_rev_take(Fr* __restrict__ q, const Fr* 
 __global__ void __launch_bounds__(256) k_two_minus(Fr* __restrict__ t, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr v = fe_neg<FrParams>(t[i]);
+    Fr v = fr_neg(t[i]);
     if (i == 0) { Fr one = fr_one(); v = fr_add(v, fr_add(one, one)); }
-    t[i] = v;
+    t[i] = fr_norm(v);
 }
 // out (plain limbs) = s*A + r*B, element-wise; A, B, s, r in Montgomery form
 __global__ void __launch_bounds__(256) k_fr_lincomb_plain(u32* __restrict__ out, const Fr* __restrict__ A, const Fr* __restrict__ B,
                                                           Fr s, Fr r, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr v = fe_from_mont<FrParams>(fr_add(fr_mul(A[i], s), fr_mul(B[i], r)));
+    u32 w[8];
+    fr_to_words8(w, fr_from_mont(fr_add(fr_mul(A[i], s), fr_mul(B[i], r))));
 #pragma unroll
-    for (int j = 0; j < 8; j++) out[8 * i + j] = v.l[j];
+    for (int j = 0; j < 8; j++) out[8 * i + j] = w[j];
 }
 __global__ void __launch_bounds__(64) k_set_one(Fr* __restrict__ p, u64 idx) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = fr_one();
@@ -298,23 +297,18 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
     // ---- factorials (host) ----
     {
-        std::vector<Fr> inv(np), v(np);
-        Fr f = fr_one(), jm = fr_zero();
-        const Fr one = fr_one();
-        std::vector<Fr> fact(np);
+        std::vector<Fr> inv(np), v(np), fact(np);
+        Fr f = fr_one();
         for (u64 j = 0; j < np; j++) {
-            if (j > 0) { jm = fr_add(jm, one); f = fr_mul(f, jm); }
+            if (j > 0) f = fr_mul(f, fr_from_u64(j));
             fact[j] = f;
         }
-        Fr finv = fe_inv<FrParams>(fact[np - 1]);
-        // walk down: 1/(j-1)! = (1/j!) * j
-        Fr jj = jm;
-        for (u64 j = np; j-- > 0;) {
+        Fr finv = fr_inv(fact[np - 1]);
+        for (u64 j = np; j-- > 0;) {  // walk down: 1/(j-1)! = (1/j!) * j
             inv[j] = finv;
-            finv = fr_mul(finv, jj);
-            jj = fr_sub(jj, one);
+            if (j > 0) finv = fr_mul(finv, fr_from_u64(j));
         }
-        for (u64 j = 0; j < np; j++) v[j] = (j & 1) ? fe_neg<FrParams>(inv[j]) : inv[j];
+        for (u64 j = 0; j < np; j++) v[j] = (j & 1) ? fr_neg(inv[j]) : inv[j];
         QT_TRY(hipMemcpyAsync(qt.invfact, inv.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
         QT_TRY(hipMemcpyAsync(qt.t1, v.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
         QT_TRY(hipStreamSynchronize(st));
