@@ -58,7 +58,7 @@ PS_INL Xyzz<F> xyzz_from_affine(const F& x, const F& y) {
 
 // 2*(x, y) for an affine point (mdbl-2008-s-1)
 template <class F>
-PS_COLD Xyzz<F> xyzz_dbl_affine(const F& x, const F& y) {
+PS_COLD Xyzz<F> xyzz_dbl_affine(F x, F y) {  // by value: a reference would pin the caller's point in scratch
     F u = f_add(y, y);
     F v = f_sqr(u);
     F w = f_mul(u, v);
@@ -75,7 +75,7 @@ PS_COLD Xyzz<F> xyzz_dbl_affine(const F& x, const F& y) {
 
 // 2*P (dbl-2008-s-1, a = 0)
 template <class F>
-PS_COLD Xyzz<F> xyzz_dbl(const Xyzz<F>& p) {
+PS_COLD Xyzz<F> xyzz_dbl(Xyzz<F> p) {
     if (xyzz_is_identity(p)) return p;
     F u = f_add(p.y, p.y);
     F v = f_sqr(u);
@@ -118,9 +118,10 @@ PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
     acc.y = y3;
 }
 
-// acc += q (add-2008-s): 12M + 2S
+// acc += q (add-2008-s): 12M + 2S.  _inl is forced inline for the latency-bound reduction kernels
+// (an out-of-line call passes both 224-byte operands through scratch memory).
 template <class F>
-PS_HD inline void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
+PS_INL void xyzz_add_inl(Xyzz<F>& acc, const Xyzz<F>& q) {
     if (xyzz_is_identity(q)) return;
     if (xyzz_is_identity(acc)) {
         acc = q;
@@ -146,6 +147,27 @@ PS_HD inline void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) {
     acc.zzz = f_mul(f_mul(acc.zzz, q.zzz), ppp);
     acc.x = x3;
     acc.y = y3;
+}
+
+template <class F>
+PS_HD inline void xyzz_add(Xyzz<F>& acc, const Xyzz<F>& q) { xyzz_add_inl<F>(acc, q); }
+
+// 2*P, forced inline (the Horner loop of the bucket reduction)
+template <class F>
+PS_INL Xyzz<F> xyzz_dbl_inl(const Xyzz<F>& p) {
+    if (xyzz_is_identity(p)) return p;
+    F u = f_add(p.y, p.y);
+    F v = f_sqr(u);
+    F w = f_mul(u, v);
+    F s = f_mul(p.x, v);
+    F xx = f_sqr(p.x);
+    F m = f_norm(f_add(f_add(xx, xx), xx));
+    Xyzz<F> r;
+    r.x = f_norm(f_sub(f_sub(f_sqr(m), s), s));
+    r.y = f_norm(f_sub(f_mul(m, f_sub(s, r.x)), f_mul(w, p.y)));
+    r.zz = f_mul(v, p.zz);
+    r.zzz = f_mul(w, p.zzz);
+    return r;
 }
 
 template <class F>

@@ -486,7 +486,7 @@ PS_HD inline Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }
 // alone (higher limbs are multiples of 2^28).  Anything else is non-zero -- the common case, ~6
 // instructions.  Survivors (probability 2^-23) take the exact path: one Montgomery reduction
 // brings V into (-p/8, 9p/8), where zero means the carried form equals 0 or p.
-PS_HD inline bool fp_is_zero_exact(const Fp& a) {
+PS_HD inline bool fp_is_zero_exact(Fp a) {
     Fp one = fp_zero();
     one.l[0] = 1;
     Fp t = fp_propagate(fp_mul_call(a, one));

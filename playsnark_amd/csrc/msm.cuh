@@ -265,7 +265,7 @@ __device__ inline void block_tree_sum(Xyzz<typename FieldTraits<KF>::Store>* sm,
     for (u32 stride = logical_block<KF>() >> 1; stride > 0; stride >>= 1) {
         if (lt < stride) {
             Xyzz<KF> a = ld_xyzz<KF>(&sm[lt]), b = ld_xyzz<KF>(&sm[lt + stride]);
-            xyzz_add<KF>(a, b);
+            xyzz_add_inl<KF>(a, b);
             st_xyzz<KF>(&sm[lt], a);
         }
         __syncthreads();
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, 
         u32 slice_start = t * (u32)M;
         u32 rs = lo > slice_start ? lo : slice_start;
         Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
-        xyzz_add<KF>(acc, part);
+        xyzz_add_inl<KF>(acc, part);
     }
     st_xyzz<KF>(&buckets[g], acc);
 }
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ off
             u32 slice_start = t * (u32)M;
             u32 rs = lo > slice_start ? lo : slice_start;
             Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
-            xyzz_add<KF>(acc, part);
+            xyzz_add_inl<KF>(acc, part);
         }
         block_tree_sum<KF>(sm, acc);
         if (logical_local<KF>() == 0) st_xyzz<KF>(&buckets[g], ld_xyzz<KF>(&sm[0]));
@@ -406,14 +406,22 @@ __global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<typename FieldT
     u32 idx = logical_tid<KF>();
     if (idx >= nseg_total) return;
     const Xyzz<typename FieldTraits<KF>::Store>* B = buckets + (size_t)idx * RED_SEG;
-    Xyzz<KF> run = xyzz_identity<KF>(), acc = xyzz_identity<KF>();
-    for (int b = RED_SEG - 1; b >= 0; b--) {
-        Xyzz<KF> v = ld_xyzz<KF>(&B[b]);
-        xyzz_add<KF>(run, v);
-        xyzz_add<KF>(acc, run);
+    // run += B[b]; acc += run  -- written as ONE inlined addition per step (x += y with the roles
+    // swapped every other step) so the kernel holds a single copy of the 14-multiplication body
+    Xyzz<KF> x = xyzz_identity<KF>(), y = ld_xyzz<KF>(&B[RED_SEG - 1]);  // x = run, y = bucket
+    Xyzz<KF> acc = xyzz_identity<KF>();
+    for (int step = 0; step < 2 * RED_SEG; step++) {
+        xyzz_add_inl<KF>(x, y);
+        if ((step & 1) == 0) {  // x was run (now updated); next: acc += run
+            Xyzz<KF> t = x; x = acc; y = t;
+        } else {                // x was acc; next: run += next bucket
+            acc = x; x = y;
+            int b = RED_SEG - 2 - (step >> 1);
+            if (b >= 0) y = ld_xyzz<KF>(&B[b]);
+        }
     }
     st_xyzz<KF>(&accs[idx], acc);
-    st_xyzz<KF>(&runs[idx], run);
+    st_xyzz<KF>(&runs[idx], x);
 }
 
 template <class KF>
@@ -430,7 +438,7 @@ __global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTrai
     if (job == 0) {
         for (u32 s = lt; s < segs_per_win; s += lb) {
             Xyzz<KF> v = ld_xyzz<KF>(&accs[(size_t)w * segs_per_win + s]);
-            xyzz_add<KF>(acc, v);
+            xyzz_add_inl<KF>(acc, v);
         }
     } else {
         const int k = (int)job - 1;  // enumerate the s with bit k set: insert a 1 at position k of t
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTrai
         for (u32 t = lt; t < (segs_per_win >> 1); t += lb) {
             u32 s = ((t & ~low) << 1) | (1u << k) | (t & low);
             Xyzz<KF> v = ld_xyzz<KF>(&runs[(size_t)w * segs_per_win + s]);
-            xyzz_add<KF>(acc, v);
+            xyzz_add_inl<KF>(acc, v);
         }
     }
     block_tree_sum<KF>(sm, acc);
@@ -452,12 +460,13 @@ __global__ void __launch_bounds__(128) k_reduce_l3(const Xyzz<typename FieldTrai
     if (w >= W) return;
     const Xyzz<typename FieldTraits<KF>::Store>* v = l2 + (size_t)w * (nbits + 1);
     Xyzz<KF> acc = xyzz_identity<KF>();
-    for (int k = nbits - 1; k >= 0; k--) {
-        acc = xyzz_dbl<KF>(acc);
-        xyzz_add<KF>(acc, ld_xyzz<KF>(&v[1 + k]));
+    // acc = 2*acc + T_k for the bit sums, then 3 more doublings and + job 0; one inlined doubling and
+    // one inlined addition serve every step (the extra steps add the identity)
+    for (int k = nbits - 1; k >= -RED_SEG_LOG - 1 + 1; k--) {
+        acc = xyzz_dbl_inl<KF>(acc);
+        Xyzz<KF> t = k >= 0 ? ld_xyzz<KF>(&v[1 + k]) : (k == -RED_SEG_LOG ? ld_xyzz<KF>(&v[0]) : xyzz_identity<KF>());
+        xyzz_add_inl<KF>(acc, t);
     }
-    for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<KF>(acc);
-    xyzz_add<KF>(acc, ld_xyzz<KF>(&v[0]));
     st_xyzz<KF>(&win_sums[w], acc);
 }
 
