@@ -66,7 +66,7 @@ struct ps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     // MSM workspace
-    DevBuf counts, offs, bsum, keys, ranks, sorted, buckets, parts, segs, wins, heavy;
+    DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy;
     DevBuf staging;                  // byte staging for uploads / downloads
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -162,7 +162,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
-                      &c->segs, &c->wins, &c->heavy, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+                      &c->segs, &c->wins, &c->heavy, &c->vals, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
     if (c->g16_pa) ps_points_free(c->g16_pa);
@@ -511,6 +511,7 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     if ((rc = c->bsum.ensure(4 * (size_t)scan_tiles + 4))) return rc;
     if ((rc = c->keys.ensure(4 * total))) return rc;
     if ((rc = c->ranks.ensure(4 * total))) return rc;
+    if ((rc = c->vals.ensure(4 * total))) return rc;
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
     if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
@@ -526,16 +527,27 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
     HIP_TRY(hipMemsetAsync(c->heavy.p, 0, 4, st));
     HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
-    hipLaunchKernelGGL(k_digits, dim3(nblocks(n)), dim3(256), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB,
-                       (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->ranks.p);
+    {
+        DigitConst cadd{};  // C = sum_{w < W-1} 2^(c*w + c-1)
+        for (int w = 0; w + 1 < pl.W; w++) {
+            int bit = w * pl.c + pl.c - 1;
+            if (bit < 256) cadd.w[bit >> 5] |= 1u << (bit & 31);
+        }
+        int bin_shift = 4;  // 16 counters = one 64-byte line
+        while ((pl.NB >> bin_shift) > (u32)DIGITS_BINS) bin_shift++;
+        dim3 grid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
+        hipLaunchKernelGGL(k_digits_grouped, grid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, scalars_ptr(sc),
+                           (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->vals.p,
+                           (u32*)c->ranks.p);
+    }
     PS_STAGE_MARK();  // 1: after memsets + digits
     hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
                        (u32*)c->bsum.p, (u64)G);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
     hipLaunchKernelGGL(k_scan_add, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (u32*)c->offs.p, (const u32*)c->bsum.p, (u64)G);
     PS_STAGE_MARK();  // 2: after scan
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->ranks.p,
-                       (const u32*)c->offs.p, (u32)n, total, (u32*)c->sorted.p);
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->vals.p,
+                       (const u32*)c->ranks.p, (const u32*)c->offs.p, total, (u32*)c->sorted.p);
     PS_STAGE_MARK();  // 3: after scatter
     hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,

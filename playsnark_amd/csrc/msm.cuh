@@ -3,8 +3,9 @@
 // (algebra.go:355-357; also groth16.go:176-178, pinochio.go:225-227).
 //
 // Pipeline (all on one HIP stream, no host round trip until the W window sums come back):
-//   1 k_digits      signed c-bit digits per scalar; a returning global atomic on the bucket
-//                   counter gives each (scalar, window) its rank inside its bucket
+//   1 k_digits_grouped  signed c-bit digits, one window x 16K scalars per workgroup, entries grouped by
+//                   counter cache line in LDS; a returning global atomic on the bucket counter gives each
+//                   entry its rank inside its bucket
 //   2 k_scan_*      exclusive prefix sum of the W*2^(c-1) bucket counters (wave shuffles + LDS)
 //   3 k_scatter     counting-sort scatter: sorted[offs[bucket] + rank] = point index | sign
 //   4 k_accumulate  the hot kernel.  Each thread owns a fixed slice of M consecutive sorted
@@ -57,62 +58,136 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
 }
 
 // ---------------------------------------------------------------------------------------
-// 1. digits
+// 1. digits + bucket ranks
 // ---------------------------------------------------------------------------------------
-PS_INL u32 limb_sel8(const u32* k, int i) {  // k[i] without dynamic register indexing
+// Signed digits are made independent of each other by adding the constant
+// C = sum_{w < W-1} 2^(c*w + c-1) once: with k' = k + C, d_w = ((k' >> cw) & mask) - 2^(c-1) for
+// w < W-1 and d_{W-1} = k' >> c(W-1) (non-negative, <= 2^(c-1)); sum d_w 2^(cw) = k.  So a
+// workgroup can compute the digits of ONE window for a chunk of scalars.
+//
+// Scattered returning atomics run at only ~2e10/s chip-wide (each lane = one 64-byte request at the
+// memory side), which used to make this the second most expensive kernel.  Here a workgroup takes
+// one window and DIGITS_CHUNK scalars, groups its entries by counter cache line in LDS (counting
+// sort on bucket >> 4), and issues the atomics in that order: the 64 lanes of a wave then touch a
+// few lines instead of 64.  Output is in block-grouped order: (key, value = index | sign, rank).
+PS_INL u32 limb_sel8(const u32* k, int i) {  // k[i] (0 beyond the end) without dynamic register indexing
     u32 v = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) v = (i == j) ? k[j] : v;
     return v;
 }
+constexpr int DIGITS_THREADS = 1024;
+constexpr int DIGITS_PER_THREAD = 16;
+constexpr int DIGITS_CHUNK = DIGITS_THREADS * DIGITS_PER_THREAD;  // 16384 scalars per workgroup
+constexpr int DIGITS_BINS = 2048;
 
-__global__ void __launch_bounds__(256) k_digits(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
-                                                u32* __restrict__ counts, u32* __restrict__ keys,
-                                                u32* __restrict__ ranks) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 k[8];
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
-    uint4 a = sp[0], b = sp[1];
-    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+__device__ inline u32 wave_incl_scan(u32 v);
+struct DigitConst { u32 w[8]; };  // the constant C above
+
+__global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
+                                                                   DigitConst cadd, int bin_shift, u32* __restrict__ counts,
+                                                                   u32* __restrict__ ent_key, u32* __restrict__ ent_val,
+                                                                   u32* __restrict__ ent_rank) {
+    __shared__ u32 hist[DIGITS_BINS];
+    __shared__ u32 wtot[DIGITS_THREADS / 64];
+    extern __shared__ __align__(16) unsigned char dg_smem[];
+    u32* lkey = reinterpret_cast<u32*>(dg_smem);
+    u32* lval = lkey + DIGITS_CHUNK;
+    const int w = blockIdx.y;
+    const u32 chunk_base = blockIdx.x * DIGITS_CHUNK;
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < DIGITS_BINS; i += DIGITS_THREADS) hist[i] = 0;
+    __syncthreads();
     const u32 mask = (1u << c) - 1u;
-    u32 carry = 0;
-    for (int w = 0; w < W; w++) {
-        int bit = w * c;
-        int li = bit >> 5, sh = bit & 31;
-        u64 two = (u64)limb_sel8(k, li) | ((u64)limb_sel8(k, li + 1) << 32);
-        u32 d = ((u32)(two >> sh) & mask) + carry;
-        u32 neg = d > NB ? 1u : 0u;
-        carry = neg;
-        if (neg) d = (1u << c) - d;
-        u32 key = 0xffffffffu, rank = 0;
-        if (d) key = (u32)w * NB + d - 1u;
-        // Skewed scalar vectors (witness values, repeated scalars, the carry-only top window) send
-        // most lanes of a wave to one bucket; a single address sustains only ~90 atomics/us.  The
-        // lanes that share the first active lane's key are served by one atomic of their count.
-        {
-            const bool act = d != 0;
-            const unsigned long long active = __ballot(act);
-            bool done = !act;
-            if (active) {
-                const int leader = __ffsll((long long)active) - 1;
-                const u32 lkey = __shfl(key, leader, 64);
-                const unsigned long long same = __ballot(act && key == lkey);
-                if (__popcll(same) > 1) {
-                    u32 base = 0;
-                    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counts[lkey], (u32)__popcll(same));
-                    base = __shfl(base, leader, 64);
-                    if (act && key == lkey) {
-                        const unsigned long long below = same & ((1ull << (threadIdx.x & 63)) - 1ull);
-                        rank = (base + (u32)__popcll(below)) | (neg << 31);
-                        done = true;
-                    }
+    const int bit = w * c, li = bit >> 5, sh = bit & 31;
+    const bool top = w == W - 1;
+    u32 dig[DIGITS_PER_THREAD];  // (magnitude-1) | sign << 31, or 0xffffffff for a zero digit
+#pragma unroll
+    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
+        const u32 i = chunk_base + j * DIGITS_THREADS + tid;
+        u32 code = 0xffffffffu;
+        if (i < n) {
+            u32 k[8];
+            const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
+            uint4 a = sp[0], b = sp[1];
+            k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+            u32 carry = 0;  // k' = k + C
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                u64 t = (u64)k[q] + cadd.w[q] + carry;
+                k[q] = (u32)t;
+                carry = (u32)(t >> 32);
+            }
+            u64 two = (u64)limb_sel8(k, li) | ((u64)limb_sel8(k, li + 1) << 32);
+            if (li == 7) two |= (u64)carry << 32;  // bit 256 of k' (only the top window can see it)
+            u32 raw = top ? (u32)(two >> sh) : ((u32)(two >> sh) & mask);
+            int d = top ? (int)raw : (int)raw - (int)NB;
+            if (d != 0) {
+                u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+                code = (mag - 1u) | (d < 0 ? 0x80000000u : 0u);
+                atomicAdd(&hist[(mag - 1u) >> bin_shift], 1u);
+            }
+        }
+        dig[j] = code;
+    }
+    __syncthreads();
+    // exclusive scan of the 2048 bins: 2 per thread
+    u32 h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    u32 inc = wave_incl_scan(h0 + h1);
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    u32 base = 0, total = 0;
+    for (int q = 0; q < DIGITS_THREADS / 64; q++) {
+        u32 t = wtot[q];
+        if (q < (int)(tid >> 6)) base += t;
+        total += t;
+    }
+    u32 ex = base + inc - (h0 + h1);
+    __syncthreads();
+    hist[2 * tid] = ex;
+    hist[2 * tid + 1] = ex + h0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
+        u32 code = dig[j];
+        if (code != 0xffffffffu) {
+            u32 m1 = code & 0x7fffffffu;
+            u32 pos = atomicAdd(&hist[m1 >> bin_shift], 1u);
+            lkey[pos] = m1;
+            lval[pos] = (chunk_base + j * DIGITS_THREADS + tid) | (code & 0x80000000u);
+        }
+    }
+    __syncthreads();
+    const size_t out = (size_t)w * n + chunk_base;
+    const u32 limit = n - chunk_base < (u32)DIGITS_CHUNK ? n - chunk_base : (u32)DIGITS_CHUNK;
+    for (u32 p0 = 0; p0 < limit; p0 += DIGITS_THREADS) {
+        const u32 p = p0 + tid;
+        u32 key = 0xffffffffu, val = 0, rank = 0;
+        const bool act = p < total;
+        if (act) { key = (u32)w * NB + lkey[p]; val = lval[p]; }
+        // lanes that share the first active lane's bucket are served by one atomic of their count
+        const unsigned long long active = __ballot(act);
+        bool done = !act;
+        if (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const u32 lk = __shfl(key, leader, 64);
+            const unsigned long long same = __ballot(act && key == lk);
+            if (__popcll(same) > 1) {
+                u32 b0 = 0;
+                if ((int)(tid & 63) == leader) b0 = atomicAdd(&counts[lk], (u32)__popcll(same));
+                b0 = __shfl(b0, leader, 64);
+                if (act && key == lk) {
+                    rank = b0 + (u32)__popcll(same & ((1ull << (tid & 63)) - 1ull));
+                    done = true;
                 }
             }
-            if (!done) rank = atomicAdd(&counts[key], 1u) | (neg << 31);
         }
-        keys[(size_t)w * n + i] = key;
-        ranks[(size_t)w * n + i] = rank;
+        if (!done) rank = atomicAdd(&counts[key], 1u);
+        if (p < limit) {
+            ent_key[out + p] = key;
+            ent_val[out + p] = val;
+            ent_rank[out + p] = rank;
+        }
     }
 }
 
@@ -201,16 +276,14 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_add(u32* __restrict__ out, 
 // ---------------------------------------------------------------------------------------
 // 3. scatter
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ keys, const u32* __restrict__ ranks,
-                                                 const u32* __restrict__ offs, u32 n, u64 total,
+__global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ ent_key, const u32* __restrict__ ent_val,
+                                                 const u32* __restrict__ ent_rank, const u32* __restrict__ offs, u64 total,
                                                  u32* __restrict__ sorted) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    u32 key = keys[idx];
+    u32 key = ent_key[idx];
     if (key == 0xffffffffu) return;
-    u32 r = ranks[idx];
-    u32 pos = offs[key] + (r & 0x7fffffffu);
-    sorted[pos] = (u32)(idx % n) | (r & 0x80000000u);
+    sorted[offs[key] + ent_rank[idx]] = ent_val[idx];
 }
 
 // ---------------------------------------------------------------------------------------
