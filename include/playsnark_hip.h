@@ -161,6 +161,25 @@ typedef struct { /* PHGR13Proof (pinochio.go:180-203) */
 int ps_phgr13_prove(ps_ctx* ctx, const ps_phgr13_ek* ek, const ps_qap* q, const ps_scalars* sol,
                     ps_phgr13_proof* out);
 
+/* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */
+typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */
+    uint8_t alpha[96];                        /* G1 */
+    uint8_t beta2[192], gamma[192], delta2[192]; /* G2 */
+    const ps_points* io_lp;                   /* IoLP, nbVars - nbIO G1 points (`diff` convention) */
+} ps_groth16_vk;
+/* Groth16Verify (groth16.go:214-233); io = sol[:diff] as in groth16_test.go:29.  *ok = 1/0. */
+int ps_groth16_verify(ps_ctx* ctx, const ps_groth16_vk* vk, const ps_scalars* io, const uint8_t A[96], const uint8_t B[192],
+                      const uint8_t C[96], int* ok);
+typedef struct { /* PHGR13VerifKey (pinochio.go:64-91); the *_io arrays are vk.vs[:diff], vk.ws[:diff], vk.ys[:diff] */
+    uint8_t av[192], aw[96], ay[192], gamma[192], bgamma[96], bgamma2[192], yts[192];
+    const ps_points *vs_io, *ws_io, *ys_io; /* G1, G2, G1 */
+} ps_phgr13_vk;
+/* PHGR13Verify (pinochio.go:281-378).  *ok = 1/0. */
+int ps_phgr13_verify(ps_ctx* ctx, const ps_phgr13_vk* vk, const ps_scalars* io, const ps_phgr13_proof* proof, int* ok);
+/* e(a1, b1) == e(a2, b2) ?  (Pair, curve.go:36-38; host only) */
+int ps_pairing_equal(const uint8_t a1_g1[96], const uint8_t b1_g2[192], const uint8_t a2_g1[96], const uint8_t b2_g2[192],
+                     int* equal);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,3 +392,40 @@ def PHGR13Prove(ek: PHGR13EvalKey, qap: QAP, solution: Poly) -> PHGR13Proof:
     s = ek._struct()
     _check(lib.ps_phgr13_prove(qap.ctx._h, C.byref(s), qap._h, solution._h, C.byref(out)))
     return PHGR13Proof(out)
+
+
+# -----------------------------------------------------------------------------------------
+# verifiers
+# -----------------------------------------------------------------------------------------
+def pairing_equal(a1: bytes, b1: bytes, a2: bytes, b2: bytes) -> bool:
+    """Pair(a1, b1).Equal(Pair(a2, b2)) (curve.go:36-38); host-only."""
+    eq = C.c_int(0)
+    _check(lib.ps_pairing_equal(a1, b1, a2, b2, C.byref(eq)))
+    return bool(eq.value)
+
+
+def Groth16Verify(ctx: Context, Alpha: bytes, Beta2: bytes, Gamma: bytes, Delta2: bytes, IoLP: Points, p: Groth16Proof,
+                  io: Poly) -> bool:
+    """func Groth16Verify(tr Groth16Setup, q QAP, p Groth16Proof, io Vector) bool (groth16.go:214)."""
+    vk = _lib.Groth16Vk()
+    for name, src in (("alpha", Alpha), ("beta2", Beta2), ("gamma", Gamma), ("delta2", Delta2)):
+        C.memmove(getattr(vk, name), src, len(src))
+    vk.io_lp = IoLP._h
+    ok = C.c_int(0)
+    _check(lib.ps_groth16_verify(ctx._h, C.byref(vk), io._h, p.A, p.B, p.C, C.byref(ok)))
+    return bool(ok.value)
+
+
+def PHGR13Verify(ctx: Context, vk_points: dict, vs_io: Points, ws_io: Points, ys_io: Points, p: "PHGR13Proof", io: Poly) -> bool:
+    """func PHGR13Verify(vk PHGR13VerifKey, qap QAP, p PHGR13Proof, io Vector) bool (pinochio.go:281).
+    vk_points: av, aw, ay, gamma, bgamma, bgamma2, yts as affine bytes."""
+    vk = _lib.Phgr13Vk()
+    for name in ("av", "aw", "ay", "gamma", "bgamma", "bgamma2", "yts"):
+        C.memmove(getattr(vk, name), vk_points[name], len(vk_points[name]))
+    vk.vs_io, vk.ws_io, vk.ys_io = vs_io._h, ws_io._h, ys_io._h
+    raw = _lib.Phgr13Proof()
+    for f in PHGR13Proof.FIELDS:
+        C.memmove(getattr(raw, f), getattr(p, f), len(getattr(p, f)))
+    ok = C.c_int(0)
+    _check(lib.ps_phgr13_verify(ctx._h, C.byref(vk), io._h, C.byref(raw), C.byref(ok)))
+    return bool(ok.value)

@@ -685,3 +685,4 @@ extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {
 }
 
 #include "prove.inc"
+#include "pairing.inc"

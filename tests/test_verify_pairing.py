@@ -91,3 +91,75 @@ def test_gpu_proofs_pass_the_reference_verifiers(ps_api, ctx, co, pr):
     pp = ps_api.PHGR13Prove(ek, q, ps_api.Poly.from_values(ctx, wit))
     tup = rs.Bag(**{f: (co.G2 if f == "wss" else co.G1).from_b(getattr(pp, f)) for f in ps_api.PHGR13Proof.FIELDS})
     assert pg.phgr13_verify(st.VK, c.nbVars - c.nbIO, tup, sol[: c.nbVars - c.nbIO])
+
+
+def test_product_pairing_is_bilinear_host_only(co, pr):
+    """ps_pairing_equal (the product's host-side Pair, curve.go:36-38) -- runs without a GPU.
+    Long scalar walks exercise the lazy-limb discipline of the Miller loop (a value carried
+    without a multiplication must be re-canonicalised, see pairing.inc)."""
+    from playsnark_amd import api
+
+    rng = pr.SplitMix64(SEED + 808)
+    g1 = lambda k: co.G1.to_b(co.G1.mul(k))
+    g2 = lambda k: co.G2.to_b(co.G2.mul(k))
+    for _ in range(3):
+        a, b = rng.fr(), rng.fr()
+        assert api.pairing_equal(g1(a), g2(b), g1(a * b % pr.R), g2(1))
+        assert api.pairing_equal(g1(a), g2(b), g1(b), g2(a))
+        assert not api.pairing_equal(g1(a), g2(b), g1((a * b + 1) % pr.R), g2(1))
+    assert api.pairing_equal(co.G1.to_b(None), g2(5), g1(7), co.G2.to_b(None))  # identity pairs to one
+
+
+@pytest.mark.gpu
+def test_product_verifiers_accept_and_reject(ps_api, ctx, co, pr):
+    """ps_groth16_verify / ps_phgr13_verify on GPU-made proofs: accept, and reject
+    the tampered proofs / public inputs of TestPinocchioInvalidProof (pinocchio_test.go:243-276);
+    the verdicts agree with the oracle's independent Python pairing."""
+    from oracle import pairing as pg
+    from oracle import restate as rs
+
+    up = lambda g, b: ps_api.Points.upload(ctx, g, b)
+    c, wit, sol, tr, trp, r, s, diff = _groth16_material(pr, co, rs, 33)
+    q = ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+    pk = ps_api.Groth16Setup(tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2, up(ps_api.G1, tr.Xi), up(ps_api.G2, tr.Xi2),
+                             up(ps_api.G1, tr.NioLP), up(ps_api.G1, tr.XiT))
+    proof = ps_api.Groth16Prove(pk, q, ps_api.Poly.upload(ctx, sol), r, s)
+    iolp = up(ps_api.G1, tr.IoLP)
+    io = ps_api.Poly.upload(ctx, sol[:diff])
+    verify = lambda p, pub: ps_api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, tr.Gamma, tr.Delta2, iolp, p, pub)
+    assert verify(proof, io)
+    assert pg.groth16_verify(trp, co.G1.from_b(proof.A), co.G2.from_b(proof.B), co.G1.from_b(proof.C), sol[:diff])
+    bad = ps_api.Groth16Proof(r, s, proof.A, proof.B, co.G1.to_b(co.G1.mul(12345)))
+    assert not verify(bad, io)
+    bad_io = list(sol[:diff])
+    bad_io[1] = (bad_io[1] + 1) % pr.R
+    assert not verify(proof, ps_api.Poly.upload(ctx, bad_io))
+    with pytest.raises(ps_api.LengthMismatch):
+        verify(proof, ps_api.Poly.upload(ctx, sol[: diff - 1]))
+
+    rng = pr.SplitMix64(SEED + 909)
+    c, wit = rs.toy_circuit()
+    sol = [pr.fr(v) for v in wit]
+    diff = c.nbVars - c.nbIO
+    st = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    ek = ps_api.PHGR13EvalKey(**{f: up(ps_api.G2 if f == "ws" else ps_api.G1, getattr(st.EK, f)) for f in ps_api.PHGR13EvalKey.FIELDS})
+    q = ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+    pp = ps_api.PHGR13Prove(ek, q, ps_api.Poly.from_values(ctx, wit))
+    vk = st.VK
+    vkb = {"av": co.G2.to_b(vk.av), "aw": co.G1.to_b(vk.aw), "ay": co.G2.to_b(vk.ay), "gamma": co.G2.to_b(vk.gamma),
+           "bgamma": co.G1.to_b(vk.bgamma), "bgamma2": co.G2.to_b(vk.bgamma2), "yts": co.G2.to_b(vk.yts)}
+    vs_io = up(ps_api.G1, co.G1.pack(vk.vs[:diff]))
+    ws_io = up(ps_api.G2, co.G2.pack(vk.ws[:diff]))
+    ys_io = up(ps_api.G1, co.G1.pack(vk.ys[:diff]))
+    io = ps_api.Poly.from_values(ctx, wit[:diff])
+    assert ps_api.PHGR13Verify(ctx, vkb, vs_io, ws_io, ys_io, pp, io)
+    rnd = co.G1.to_b(co.G1.mul(rng.fr()))
+    for field in ("yss", "vss", "hs", "gz", "vass"):  # pinocchio_test.go:243-262
+        saved = getattr(pp, field)
+        setattr(pp, field, rnd)
+        assert not ps_api.PHGR13Verify(ctx, vkb, vs_io, ws_io, ys_io, pp, io), field
+        setattr(pp, field, saved)
+    for key in ("bgamma2", "av", "ay"):  # pinocchio_test.go:265-276 (random VK element)
+        tampered = dict(vkb)
+        tampered[key] = co.G2.to_b(co.G2.mul(rng.fr()))
+        assert not ps_api.PHGR13Verify(ctx, tampered, vs_io, ws_io, ys_io, pp, io), key
