@@ -161,6 +161,16 @@ typedef struct { /* PHGR13Proof (pinochio.go:180-203) */
 int ps_phgr13_prove(ps_ctx* ctx, const ps_phgr13_ek* ek, const ps_qap* q, const ps_scalars* sol,
                     ps_phgr13_proof* out);
 
+/* ---- trusted setup on the device ---- */
+typedef struct { uint8_t alpha[32], beta[32], delta[32], x[32], gamma[32]; } ps_groth16_toxic; /* groth16.go:15-26 */
+typedef struct { /* type Groth16Setup (groth16.go:30-61) without the toxic waste */
+    uint8_t alpha[96], beta[96], delta[96];        /* G1 */
+    uint8_t beta2[192], delta2[192], gamma[192];   /* G2 */
+    ps_points *xi, *xi2, *io_lp, *nio_lp, *xi_t;    /* caller frees with ps_points_free */
+} ps_groth16_crs;
+/* NewGroth16TrustedSetup (groth16.go:64-101) with the toxic waste supplied by the caller. */
+int ps_groth16_setup(ps_ctx* ctx, const ps_qap* q, const ps_groth16_toxic* tw, ps_groth16_crs* out);
+
 /* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */
 typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */
     uint8_t alpha[96];                        /* G1 */

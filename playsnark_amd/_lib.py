@@ -28,7 +28,7 @@ SYMBOLS = [
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
-    "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal",
+    "ps_groth16_setup", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal",
 ]
 
 
@@ -45,6 +45,16 @@ class Groth16Pk(C.Structure):
     _fields_ = [("alpha", C.c_uint8 * 96), ("beta", C.c_uint8 * 96), ("delta", C.c_uint8 * 96),
                 ("beta2", C.c_uint8 * 192), ("delta2", C.c_uint8 * 192),
                 ("xi", C.c_void_p), ("xi2", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p)]
+
+
+class Groth16Toxic(C.Structure):
+    _fields_ = [(n, C.c_uint8 * 32) for n in ("alpha", "beta", "delta", "x", "gamma")]
+
+
+class Groth16Crs(C.Structure):
+    _fields_ = [("alpha", C.c_uint8 * 96), ("beta", C.c_uint8 * 96), ("delta", C.c_uint8 * 96),
+                ("beta2", C.c_uint8 * 192), ("delta2", C.c_uint8 * 192), ("gamma", C.c_uint8 * 192),
+                ("xi", C.c_void_p), ("xi2", C.c_void_p), ("io_lp", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p)]
 
 
 class Groth16Vk(C.Structure):
@@ -124,6 +134,7 @@ def _load():
     lib.ps_groth16_prove.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_char_p, C.c_char_p]
     lib.ps_phgr13_prove.argtypes = [vp, C.POINTER(Phgr13Ek), vp, vp, C.POINTER(Phgr13Proof)]
+    lib.ps_groth16_setup.argtypes = [vp, vp, C.POINTER(Groth16Toxic), C.POINTER(Groth16Crs)]
     lib.ps_groth16_verify.argtypes = [vp, C.POINTER(Groth16Vk), vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
     lib.ps_phgr13_verify.argtypes = [vp, C.POINTER(Phgr13Vk), vp, C.POINTER(Phgr13Proof), C.POINTER(C.c_int)]
     lib.ps_pairing_equal.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]

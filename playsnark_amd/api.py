@@ -342,6 +342,21 @@ class Groth16Setup:
         return pk
 
 
+def NewGroth16TrustedSetup(qap: "QAP", alpha: int, beta: int, delta: int, x: int, gamma: int):
+    """func NewGroth16TrustedSetup(qap QAP) Groth16Setup (groth16.go:64) on the device; the toxic
+    waste is drawn by the caller (the reference draws it at :67-84).  Returns (Groth16Setup for the
+    prover, dict with Gamma / IoLP for the verifier)."""
+    tw = _lib.Groth16Toxic()
+    for name, v in (("alpha", alpha), ("beta", beta), ("delta", delta), ("x", x), ("gamma", gamma)):
+        C.memmove(getattr(tw, name), _be32(v), 32)
+    crs = _lib.Groth16Crs()
+    _check(lib.ps_groth16_setup(qap.ctx._h, qap._h, C.byref(tw), C.byref(crs)))
+    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in ("xi", "xi2", "io_lp", "nio_lp", "xi_t")}
+    tr = Groth16Setup(bytes(crs.alpha), bytes(crs.beta), bytes(crs.delta), bytes(crs.beta2), bytes(crs.delta2),
+                      pts["xi"], pts["xi2"], pts["nio_lp"], pts["xi_t"])
+    return tr, {"Gamma": bytes(crs.gamma), "IoLP": pts["io_lp"]}
+
+
 class Groth16Proof:
     """type Groth16Proof (groth16.go:106-118); tp = (R, S) as supplied."""
 

@@ -193,6 +193,48 @@ __global__ void __launch_bounds__(256) k_fr_lincomb_plain(u32* __restrict__ out,
 #pragma unroll
     for (int j = 0; j < 8; j++) out[8 * i + j] = w[j];
 }
+// ---- trusted-setup helpers ----
+struct FrPow2Table { Fr p[32]; };  // p[k] = x^(2^k)
+// out[i] = shift * x^i  (GeneratePowersCommit's exponents, algebra.go:371-384)
+__global__ void __launch_bounds__(256) k_fr_powers(Fr* __restrict__ out, FrPow2Table tab, Fr shift, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr acc = shift;
+    for (int k = 0; k < 32; k++)
+        if ((i >> k) & 1) acc = fr_mul(acc, tab.p[k]);
+    out[i] = acc;
+}
+// l_j(x) = zx * w_j / (x - j), w_j = (-1)^(n-j) / ((j-1)! (n-j)!), j = 1..n   (the Lagrange basis
+// behind Interpolate, algebra.go:254-338, evaluated at the secret point)
+__global__ void __launch_bounds__(256) k_lagrange_at(Fr* __restrict__ out, const Fr* __restrict__ invfact, Fr x, Fr zx, u64 n) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    u64 j = idx + 1;
+    Fr d = fr_inv(fr_norm(fr_sub(x, fr_from_u64(j))));
+    Fr w = fr_mul(invfact[j - 1], invfact[n - j]);
+    if ((n - j) & 1) w = fr_neg(w);
+    out[idx] = fr_mul(fr_mul(zx, w), d);
+}
+// partial products of (x - j), j = 1..n: one value per block
+__global__ void __launch_bounds__(256) k_prod_x_minus_j(Fr* __restrict__ partial, Fr x, u64 n) {
+    __shared__ Fr sm[256];
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    sm[threadIdx.x] = idx < n ? fr_norm(fr_sub(x, fr_from_u64(idx + 1))) : fr_one();
+    __syncthreads();
+    for (u32 stride = 128; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) sm[threadIdx.x] = fr_mul(sm[threadIdx.x], sm[threadIdx.x + stride]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+// out[i] = (beta*u[i] + alpha*v[i] + w[i]) * (i < diff ? ginv : dinv)   (linearPolyForVar, groth16.go:238-250)
+__global__ void __launch_bounds__(256) k_linear_poly(Fr* __restrict__ out, const Fr* __restrict__ u, const Fr* __restrict__ v,
+                                                     const Fr* __restrict__ w, Fr alpha, Fr beta, Fr ginv, Fr dinv, u64 diff, u64 m) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    Fr lp = fr_norm(fr_add(fr_add(fr_mul(beta, u[i]), fr_mul(alpha, v[i])), w[i]));
+    out[i] = fr_mul(lp, i < diff ? ginv : dinv);
+}
 __global__ void __launch_bounds__(64) k_set_one(Fr* __restrict__ p, u64 idx) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = fr_one();
 }

@@ -182,3 +182,36 @@ def test_phgr13_proof_bit_identical(ps_api, ctx, co, pr, n):
         assert getattr(proof, f) == getattr(want, f), f
     # hs == h(s)*G  (pinocchio_test.go:33-44)
     assert proof.hs == co.G1.to_b(co.G1.mul(pr.poly_eval(want.h, setup.t.s)))
+
+
+@pytest.mark.parametrize("n", [4, 37, 200])
+def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
+    """NewGroth16TrustedSetup (groth16.go:64-101) on the device against the oracle: every CRS array
+    byte-identical (Xi, Xi2, IoLP, NioLP, XiT and the six fixed points), then a proof made with the
+    device CRS equals the oracle's proof."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 64 + n)
+    if n == 4:
+        c, wit = rs.toy_circuit()
+        sol = [pr.fr(v) for v in wit]
+    else:
+        c, sol = rs.synthetic_circuit(n)
+    tox = [rng.fr() for _ in range(5)]
+    want = rs.groth16_setup(c, *tox)
+    q = _upload_circuit(ps_api, ctx, c)
+    tr, vk = ps_api.NewGroth16TrustedSetup(q, *tox)
+    assert (tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2, vk["Gamma"]) == (
+        want.Alpha, want.Beta, want.Delta, want.Beta2, want.Delta2, want.Gamma)
+    assert tr.Xi.download() == want.Xi
+    assert tr.Xi2.download() == want.Xi2
+    assert tr.XiT.download() == want.XiT
+    assert tr.NioLP.download() == want.NioLP
+    assert vk["IoLP"].download() == want.IoLP
+    r, s = rng.fr(), rng.fr()
+    proof = ps_api.Groth16Prove(tr, q, ps_api.Poly.upload(ctx, sol), r, s)
+    ref = rs.groth16_prove(want, c, sol, r, s, fast=n > 16)
+    assert (proof.A, proof.B, proof.C) == (ref.A, ref.B, ref.C)
+    # x on the interpolation domain is refused (a Lagrange denominator would vanish)
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.NewGroth16TrustedSetup(q, tox[0], tox[1], tox[2], 3, tox[4])

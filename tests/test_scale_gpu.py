@@ -38,29 +38,25 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     u, v, w, zx = rs.var_poly_evals(c, x)
     t["host_circuit_and_setup_scalars_s"] = time.time() - t0
 
-    # ---- CRS on the device: GeneratePowersCommit / fullLinearPoly (algebra.go:371-384, groth16.go:254-264)
-    t0 = time.time()
+    # ---- CRS on the device: NewGroth16TrustedSetup (groth16.go:64-101), toxic waste retained for the checks
     up = lambda vals: ps_api.Poly.upload(ctx, vals)
     g1 = lambda vals: ps_api.Points.from_scalars(ctx, ps_api.G1, up(vals))
-    g2 = lambda vals: ps_api.Points.from_scalars(ctx, ps_api.G2, up(vals))
-    xi_s = _powers(x, n, 1, R)
-    Xi, Xi2 = g1(xi_s), g2(xi_s)
-    txd = pr.fr_div(zx, delta)
-    XiT = g1(_powers(x, n - 1, txd, R))
-    nio_s = [pr.fr_div((w[i] + beta * u[i] + alpha * v[i]) % R, delta) for i in range(diff, m)]
-    NioLP = g1(nio_s)
     one = lambda grp, k: grp.to_b(grp.mul(k))
-    tr = ps_api.Groth16Setup(one(co.G1, alpha), one(co.G1, beta), one(co.G1, delta), one(co.G2, beta), one(co.G2, delta),
-                             Xi, Xi2, NioLP, XiT)
-    ctx.sync()
-    t["device_crs_s"] = time.time() - t0
-    # spot-check the device CRS against the oracle
-    assert Xi.download(5, 1) == one(co.G1, xi_s[5]) and Xi2.download(n - 1, 1) == one(co.G2, xi_s[n - 1])
-
     t0 = time.time()
     q = ps_api.QAP(ctx, m, c.nbIO, c.left, c.right, c.out)
     ctx.sync()
     t["qap_create_s"] = time.time() - t0
+    t0 = time.time()
+    tr, vk = ps_api.NewGroth16TrustedSetup(q, alpha, beta, delta, x, gamma)
+    ctx.sync()
+    t["device_setup_s"] = time.time() - t0
+    # spot-check the device CRS against scalars recomputed on the host
+    xi_s = _powers(x, n, 1, R)
+    assert tr.Xi.download(5, 1) == one(co.G1, xi_s[5]) and tr.Xi2.download(n - 1, 1) == one(co.G2, xi_s[n - 1])
+    assert tr.XiT.download(n - 2, 1) == one(co.G1, xi_s[n - 2] * pr.fr_div(zx, delta) % R)
+    lin = lambda i, div: pr.fr_div((w[i] + beta * u[i] + alpha * v[i]) % R, div)
+    assert tr.NioLP.download() == b"".join(one(co.G1, lin(i, delta)) for i in range(diff, m))
+    assert vk["IoLP"].download(7, 1) == one(co.G1, lin(7, gamma)) and len(vk["IoLP"]) == diff
     dsol = up(sol)
 
     r, s = rng.fr(), rng.fr()
