@@ -145,16 +145,39 @@ __global__ void __launch_bounds__(256) k_tree_take_left(Fr* __restrict__ zhat, c
 // ---------------------------------------------------------------------------------------
 // per-proof kernels
 // ---------------------------------------------------------------------------------------
+constexpr u32 SPMV_LONG_ROW = 512;  // rows with more non-zeros are summed by a whole workgroup
+
 __global__ void __launch_bounds__(256) k_spmv(const u32* __restrict__ row_ptr, const u32* __restrict__ col,
                                               const Fr* __restrict__ val, const Fr* __restrict__ x, Fr* __restrict__ y, u32 n) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
+    if (row_ptr[r + 1] - row_ptr[r] > SPMV_LONG_ROW) return;  // k_spmv_long_rows owns it
     Fr acc = fr_zero();
     for (u32 e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
         acc = fr_norm(fr_add(acc, fr_mul(val[e], x[col[e]])));
         if (((e - row_ptr[r]) & 31u) == 31u) acc = fr_reduce(acc);  // dense rows: keep |value| small
     }
     y[r] = acc;
+}
+// one workgroup per long row (e.g. the `const` variable's column in a transposed R1CS matrix)
+__global__ void __launch_bounds__(256) k_spmv_long_rows(const u32* __restrict__ row_ptr, const u32* __restrict__ col,
+                                                        const Fr* __restrict__ val, const Fr* __restrict__ x, Fr* __restrict__ y,
+                                                        const u32* __restrict__ long_rows) {
+    __shared__ Fr sm[256];
+    const u32 r = long_rows[blockIdx.x];
+    Fr acc = fr_zero();
+    u32 cnt = 0;
+    for (u32 e = row_ptr[r] + threadIdx.x; e < row_ptr[r + 1]; e += blockDim.x) {
+        acc = fr_norm(fr_add(acc, fr_mul(val[e], x[col[e]])));
+        if ((++cnt & 31u) == 0) acc = fr_reduce(acc);
+    }
+    sm[threadIdx.x] = fr_reduce(acc);
+    __syncthreads();
+    for (u32 stride = 128; stride > 0; stride >>= 1) {
+        if (threadIdx.x < stride) sm[threadIdx.x] = fr_norm(fr_add(sm[threadIdx.x], sm[threadIdx.x + stride]));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) y[r] = sm[0];
 }
 __global__ void __launch_bounds__(256) k_check_gates(const Fr* __restrict__ yA, const Fr* __restrict__ yB,
                                                      const Fr* __restrict__ yC, u32 n, u32* __restrict__ flag) {
