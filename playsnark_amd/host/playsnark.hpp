@@ -165,4 +165,23 @@ inline ps_phgr13_proof PHGR13Prove(Context& c, const ps_phgr13_ek& ek, const QAP
     return out;
 }
 
+// func Groth16Verify(tr Groth16Setup, q QAP, p Groth16Proof, io Vector) bool (groth16.go:214)
+inline bool Groth16Verify(Context& c, const ps_groth16_vk& vk, const Groth16Proof& p, const Poly& io) {
+    int ok = 0;
+    check(ps_groth16_verify(c.get(), &vk, io.get(), p.A.data(), p.B.data(), p.C.data(), &ok));
+    return ok != 0;
+}
+// func PHGR13Verify(vk PHGR13VerifKey, qap QAP, p PHGR13Proof, io Vector) bool (pinochio.go:281)
+inline bool PHGR13Verify(Context& c, const ps_phgr13_vk& vk, const ps_phgr13_proof& p, const Poly& io) {
+    int ok = 0;
+    check(ps_phgr13_verify(c.get(), &vk, io.get(), &p, &ok));
+    return ok != 0;
+}
+// func NewGroth16TrustedSetup(qap QAP) Groth16Setup (groth16.go:64), toxic waste drawn by the caller
+inline ps_groth16_crs NewGroth16TrustedSetup(Context& c, const QAP& q, const ps_groth16_toxic& tw) {
+    ps_groth16_crs out;
+    check(ps_groth16_setup(c.get(), q.get(), &tw, &out));
+    return out;
+}
+
 }  // namespace playsnark
