@@ -92,6 +92,12 @@ int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, siz
  * leaves the per-window sums on the device; ps_msm_finish() waits and folds them on the host. */
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);
+/* k sums over ONE scalar vector: out[i] = sum_j scalars[j] * points[i][j].  The digit sort runs once and
+ * is shared; the arrays may mix G1 and G2.  This is the shape of computeSolCommit called nine times on
+ * solution[diff:] (pinochio.go:231-241).  k <= PS_MSM_MULTI_MAX; every array must have the scalars'
+ * length (PS_ERR_LENGTH otherwise, algebra.go:350-352). */
+#define PS_MSM_MULTI_MAX 16
+int ps_msm_multi(ps_ctx* ctx, const ps_points* const* points, size_t k, const ps_scalars* scalars, uint8_t* const* out);
 /* Host-side conversion of ONE point between PS_FMT_AFFINE and PS_FMT_COMPRESSED (what the shim
  * needs to feed proof elements back to kyber's UnmarshalBinary).  Validates the encoding. */
 int ps_point_convert(int group, int in_fmt, int out_fmt, const uint8_t* in, uint8_t* out);
@@ -170,6 +176,16 @@ typedef struct { /* type Groth16Setup (groth16.go:30-61) without the toxic waste
 } ps_groth16_crs;
 /* NewGroth16TrustedSetup (groth16.go:64-101) with the toxic waste supplied by the caller. */
 int ps_groth16_setup(ps_ctx* ctx, const ps_qap* q, const ps_groth16_toxic* tw, ps_groth16_crs* out);
+
+typedef struct { uint8_t s[32], av[32], aw[32], ay[32], rv[32], rw[32], beta[32], gamma[32]; } ps_phgr13_toxic; /* draw order of pinochio.go:99-138 */
+typedef struct { /* PHGR13Setup (pinochio.go:28-35) without the toxic waste */
+    ps_points *gsi, *vs, *ws, *ys, *vas, *was, *yas, *vbs, *wbs, *ybs;                  /* PHGR13EvalKey, pinochio.go:37-62 */
+    uint8_t av[192], aw[96], ay[192], gamma[192], bgamma[96], bgamma2[192], yts[192]; /* PHGR13VerifKey, pinochio.go:64-91 */
+    ps_points *vk_vs, *vk_ws, *vk_ys; /* vk.vs, vk.ws (G2), vk.ys over ALL variables; vs/ws/ys above are their [diff:] views */
+} ps_phgr13_crs;
+/* NewPHGR13TrustedSetup (pinochio.go:93-176) with the toxic waste supplied by the caller. */
+int ps_phgr13_setup(ps_ctx* ctx, const ps_qap* q, const ps_phgr13_toxic* tw, ps_phgr13_crs* out);
+void ps_phgr13_crs_free(ps_phgr13_crs* crs); /* frees the 13 arrays */
 
 /* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */
 typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */

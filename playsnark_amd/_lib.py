@@ -25,10 +25,10 @@ SYMBOLS = [
     "ps_points_slice", "ps_points_free",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
-    "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_points_sum", "ps_point_convert",
+    "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
-    "ps_groth16_setup", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal",
+    "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal",
 ]
 
 
@@ -70,6 +70,17 @@ class Phgr13Vk(C.Structure):
 
 class Phgr13Ek(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("vs", "ws", "ys", "vas", "was", "yas", "gsi", "vbs", "wbs", "ybs")]
+
+
+class Phgr13Toxic(C.Structure):
+    _fields_ = [(n, C.c_uint8 * 32) for n in ("s", "av", "aw", "ay", "rv", "rw", "beta", "gamma")]
+
+
+class Phgr13Crs(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("gsi", "vs", "ws", "ys", "vas", "was", "yas", "vbs", "wbs", "ybs")] +
+                [("av", C.c_uint8 * 192), ("aw", C.c_uint8 * 96), ("ay", C.c_uint8 * 192), ("gamma", C.c_uint8 * 192),
+                 ("bgamma", C.c_uint8 * 96), ("bgamma2", C.c_uint8 * 192), ("yts", C.c_uint8 * 192)] +
+                [(n, C.c_void_p) for n in ("vk_vs", "vk_ws", "vk_ys")])
 
 
 class Phgr13Proof(C.Structure):
@@ -119,6 +130,7 @@ def _load():
     lib.ps_msm_i64.argtypes = [vp, vp, vp, sz, C.c_char_p]
     lib.ps_msm_launch.argtypes = [vp, vp, vp]
     lib.ps_msm_finish.argtypes = [vp, C.c_char_p]
+    lib.ps_msm_multi.argtypes = [vp, C.POINTER(vp), C.c_size_t, vp, C.POINTER(vp)]
     lib.ps_points_sum.argtypes = [i, C.c_char_p, sz, C.c_char_p]
     lib.ps_point_convert.argtypes = [i, i, i, C.c_char_p, C.c_char_p]
     lib.ps_msm_last_info.argtypes = [vp, C.POINTER(MsmInfo)]
@@ -135,6 +147,9 @@ def _load():
                                      C.c_char_p, C.c_char_p]
     lib.ps_phgr13_prove.argtypes = [vp, C.POINTER(Phgr13Ek), vp, vp, C.POINTER(Phgr13Proof)]
     lib.ps_groth16_setup.argtypes = [vp, vp, C.POINTER(Groth16Toxic), C.POINTER(Groth16Crs)]
+    lib.ps_phgr13_setup.argtypes = [vp, vp, C.POINTER(Phgr13Toxic), C.POINTER(Phgr13Crs)]
+    lib.ps_phgr13_crs_free.argtypes = [C.POINTER(Phgr13Crs)]
+    lib.ps_phgr13_crs_free.restype = None
     lib.ps_groth16_verify.argtypes = [vp, C.POINTER(Groth16Vk), vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
     lib.ps_phgr13_verify.argtypes = [vp, C.POINTER(Phgr13Vk), vp, C.POINTER(Phgr13Proof), C.POINTER(C.c_int)]
     lib.ps_pairing_equal.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]

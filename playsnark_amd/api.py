@@ -239,6 +239,17 @@ def msm_finish(ctx: Context, group: int) -> bytes:
     return out.raw
 
 
+def msm_multi(ctx: Context, points: list, scalars: Poly) -> list:
+    """[scalars.BlindEval(p) for p in points] with one digit sort shared by all arrays (ps_msm_multi):
+    the nine computeSolCommit calls of PHGR13Prove (pinochio.go:231-241) have this shape."""
+    k = len(points)
+    outs = [C.create_string_buffer(_WIRE[p.group]) for p in points]
+    pa = (C.c_void_p * max(k, 1))(*[p._h for p in points])
+    oa = (C.c_void_p * max(k, 1))(*[C.cast(o, C.c_void_p) for o in outs])
+    _check(lib.ps_msm_multi(ctx._h, pa, k, scalars._h, oa))
+    return [o.raw for o in outs]
+
+
 def point_convert(group: int, raw: bytes, in_fmt: int, out_fmt: int) -> bytes:
     """One point between the ZCash uncompressed and compressed forms (kyber MarshalBinary)."""
     out = C.create_string_buffer(_WIRE[group] if out_fmt == _lib.PS_FMT_AFFINE else _WIRE[group] // 2)
@@ -389,6 +400,34 @@ class PHGR13EvalKey:
         for f in self.FIELDS:
             setattr(ek, f, getattr(self, f)._h)
         return ek
+
+
+class PHGR13VerifKey:
+    """type PHGR13VerifKey (pinochio.go:64-91): fixed points as affine bytes, vs/ws/ys over all variables."""
+
+    FIXED = ("av", "aw", "ay", "gamma", "bgamma", "bgamma2", "yts")
+
+    def __init__(self, vs: Points, ws: Points, ys: Points, **fixed):
+        self.vs, self.ws, self.ys = vs, ws, ys
+        for f in self.FIXED:
+            setattr(self, f, fixed[f])
+
+    def fixed_points(self) -> dict:
+        return {f: getattr(self, f) for f in self.FIXED}
+
+
+def NewPHGR13TrustedSetup(qap: "QAP", s: int, av: int, aw: int, ay: int, rv: int, rw: int, beta: int, gamma: int):
+    """func NewPHGR13TrustedSetup(qap QAP) PHGR13Setup (pinochio.go:93) on the device; the toxic waste
+    is drawn by the caller, in the reference's draw order (:99-138).  Returns (EK, VK)."""
+    tw = _lib.Phgr13Toxic()
+    for name, v in (("s", s), ("av", av), ("aw", aw), ("ay", ay), ("rv", rv), ("rw", rw), ("beta", beta), ("gamma", gamma)):
+        C.memmove(getattr(tw, name), _be32(v), 32)
+    crs = _lib.Phgr13Crs()
+    _check(lib.ps_phgr13_setup(qap.ctx._h, qap._h, C.byref(tw), C.byref(crs)))
+    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in PHGR13EvalKey.FIELDS + ("vk_vs", "vk_ws", "vk_ys")}
+    ek = PHGR13EvalKey(**{f: pts[f] for f in PHGR13EvalKey.FIELDS})
+    vk = PHGR13VerifKey(pts["vk_vs"], pts["vk_ws"], pts["vk_ys"], **{f: bytes(getattr(crs, f)) for f in PHGR13VerifKey.FIXED})
+    return ek, vk
 
 
 class PHGR13Proof:

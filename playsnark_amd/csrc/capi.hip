@@ -62,6 +62,8 @@ struct DevBuf {
     }
 };
 
+constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>);  // window sums of one MSM (W <= 64)
+
 struct ps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -88,10 +90,14 @@ struct ps_ctx {
     uint8_t g16_fixed[96 * 3 + 192 * 2] = {0};
     ps_points *g16_pa = nullptr, *g16_pb = nullptr, *g16_pc = nullptr;
     hipEvent_t g16_ready = nullptr;
+    // PHGR13 driver: vbs + wbs + ybs summed pointwise once per evaluation key (gz, pinochio.go:239-242)
+    unsigned long long phgr_key[3] = {0, 0, 0};
+    ps_points* phgr_bsum = nullptr;
     // optional per-stage timing (HIP events on `stream`, the stream the kernels run on)
     bool timing = false;
     hipEvent_t ev[PS_MSM_STAGES + 1] = {};
     bool ev_valid = false;
+    hipEvent_t ev_multi[PS_MSM_MULTI_MAX] = {};  // one per result of ps_msm_multi (created on first use)
 };
 
 struct Storage {  // shared device allocation behind slices
@@ -150,7 +156,7 @@ extern "C" int ps_ctx_create(int device, ps_ctx** out) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void**)&c->d_flag, 64));
-    c->h_pinned_cap = 64 * sizeof(Xyzz<Fp2>) + 64;
+    c->h_pinned_cap = PS_MSM_MULTI_MAX * PS_PINNED_SLOT + 64;
     HIP_TRY(hipHostMalloc(&c->h_pinned, c->h_pinned_cap));
     for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
@@ -169,8 +175,10 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (c->g16_pb) ps_points_free(c->g16_pb);
     if (c->g16_pc) ps_points_free(c->g16_pc);
     if (c->g16_ready) (void)hipEventDestroy(c->g16_ready);
+    if (c->phgr_bsum) ps_points_free(c->phgr_bsum);
     if (c->aux) ps_ctx_destroy(c->aux);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_multi) if (e) (void)hipEventDestroy(e);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -492,18 +500,14 @@ extern "C" int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* o
 // ---------------------------------------------------------------------------------------
 // MSM driver
 // ---------------------------------------------------------------------------------------
-template <class F>
-static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl) {
-    typedef typename KernelField<F>::type KF;      // Fp -> Fp, Fp2 -> lane-split Fp2s
-    constexpr unsigned LN = FieldTraits<KF>::LANES;  // lanes per logical thread
+// The pipeline is split in two: the sort (digits, scan, scatter) depends on the scalars only, the
+// point pass (accumulate, fixup, reduce) on one point array.  ps_msm_multi runs one sort for several
+// point arrays that share a scalar vector (computeSolCommit x9, pinochio.go:231-241).
+#define PS_STAGE_MARK() do { if (timed) HIP_TRY(hipEventRecord(c->ev[evi++], st)); } while (0)
+static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool timed) {
     const size_t n = sc->n;
     const u64 total = (u64)pl.W * n;  // upper bound on entries
     const u64 G = pl.G;
-    const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
-    const u32 segs_per_win = pl.NB >> RED_SEG_LOG;
-    const u32 nseg_total = segs_per_win * (u32)pl.W;
-    const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
-    const u32 l2_jobs = (u32)pl.W * (u32)(red_bits + 1);
     const u32 scan_tiles = (u32)((G + SCAN_TILE - 1) / SCAN_TILE);
     int rc;
     if ((rc = c->counts.ensure(4 * G))) return rc;
@@ -513,20 +517,10 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     if ((rc = c->ranks.ensure(4 * total))) return rc;
     if ((rc = c->vals.ensure(4 * total))) return rc;
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
-    if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
-    if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
-    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
-    if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
-    const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
-    if ((rc = c->heavy.ensure(4 * (max_heavy + 1)))) return rc;
-    if (sizeof(Xyzz<F>) * (size_t)pl.W + 64 > c->h_pinned_cap) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = c->stream;
     int evi = 0;
-#define PS_STAGE_MARK() do { if (c->timing) HIP_TRY(hipEventRecord(c->ev[evi++], st)); } while (0)
     PS_STAGE_MARK();  // 0: start
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
-    HIP_TRY(hipMemsetAsync(c->heavy.p, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     {
         DigitConst cadd{};  // C = sum_{w < W-1} 2^(c*w + c-1)
         for (int w = 0; w + 1 < pl.W; w++) {
@@ -540,7 +534,7 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
                            (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->vals.p,
                            (u32*)c->ranks.p);
     }
-    PS_STAGE_MARK();  // 1: after memsets + digits
+    PS_STAGE_MARK();  // 1: after memset + digits
     hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
                        (u32*)c->bsum.p, (u64)G);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
@@ -549,6 +543,36 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->vals.p,
                        (const u32*)c->ranks.p, (const u32*)c->offs.p, total, (u32*)c->sorted.p);
     PS_STAGE_MARK();  // 3: after scatter
+    HIP_TRY(hipGetLastError());
+    // entry count for introspection (read back with the window sums)
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + c->h_pinned_cap - 8, (u32*)c->offs.p + G, 4, hipMemcpyDeviceToHost, st));
+    return PS_OK;
+}
+
+// window sums of one point array over the sorted entries, copied to pinned slot `slot`
+template <class F>
+static int msm_points_t(ps_ctx* c, const ps_points* pts, size_t n, const MsmPlan& pl, bool timed, int slot) {
+    typedef typename KernelField<F>::type KF;      // Fp -> Fp, Fp2 -> lane-split Fp2s
+    constexpr unsigned LN = FieldTraits<KF>::LANES;  // lanes per logical thread
+    const u64 total = (u64)pl.W * n;
+    const u64 G = pl.G;
+    const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
+    const u32 segs_per_win = pl.NB >> RED_SEG_LOG;
+    const u32 nseg_total = segs_per_win * (u32)pl.W;
+    const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
+    const u32 l2_jobs = (u32)pl.W * (u32)(red_bits + 1);
+    int rc;
+    if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
+    if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
+    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
+    if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
+    const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
+    if ((rc = c->heavy.ensure(4 * (max_heavy + 1)))) return rc;
+    if (sizeof(Xyzz<F>) * (size_t)pl.W > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
+    hipStream_t st = c->stream;
+    int evi = 4;
+    HIP_TRY(hipMemsetAsync(c->heavy.p, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,
                        (Xyzz<F>*)c->parts.p);
@@ -571,24 +595,73 @@ static int msm_launch_t(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, c
                            (Xyzz<F>*)c->wins.p);
     }
     PS_STAGE_MARK();  // 6: after reduction
-#undef PS_STAGE_MARK
-    c->ev_valid = c->timing;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_pinned, c->wins.p, sizeof(Xyzz<F>) * pl.W, hipMemcpyDeviceToHost, st));
-    // entry count for introspection (read back with the window sums)
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + c->h_pinned_cap - 8, (u32*)c->offs.p + G, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, c->wins.p, sizeof(Xyzz<F>) * pl.W,
+                           hipMemcpyDeviceToHost, st));
     return PS_OK;
+}
+#undef PS_STAGE_MARK
+
+static int msm_launch_any(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl) {
+    int rc = msm_sort(c, sc, pl, c->timing);
+    if (rc) return rc;
+    rc = pts->group == PS_G1 ? msm_points_t<Fp>(c, pts, sc->n, pl, c->timing, 0) : msm_points_t<Fp2>(c, pts, sc->n, pl, c->timing, 0);
+    c->ev_valid = c->timing && !rc;
+    return rc;
 }
 
 template <class F>
-static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, uint8_t* out) {
-    const Xyzz<F>* wins = (const Xyzz<F>*)c->h_pinned;
+static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) {
+    const Xyzz<F>* wins = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
     Xyzz<F> acc = xyzz_identity<F>();
     for (int w = pl.W - 1; w >= 0; w--) {
         for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
         xyzz_add<F>(acc, wins[w]);
     }
     write_affine(out, acc);
+}
+
+static void write_identity(int group, uint8_t* out) {  // zero.Clone(), algebra.go:353
+    memset(out, 0, wire_bytes(group));
+    out[0] = 0x40;
+}
+
+extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, const ps_scalars* sc, uint8_t* const* out) {
+    if (!c || !pts || !sc || !out) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
+    if (k == 0) return PS_OK;
+    if (k > PS_MSM_MULTI_MAX) return fail(PS_ERR_ARG, "ps_msm_multi: more than PS_MSM_MULTI_MAX point arrays");
+    for (size_t i = 0; i < k; i++) {
+        if (!pts[i] || !out[i]) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
+        if (pts[i]->n != sc->n)  // algebra.go:350-352
+            return fail(PS_ERR_LENGTH, "mismatch of length between poly " + std::to_string(sc->n) + " and blinded eval points " +
+                                           std::to_string(pts[i]->n));
+    }
+    if (c->pending) return fail(PS_ERR_ARG, "ps_msm_multi: an MSM is already pending on this context");
+    if (sc->n == 0) {
+        for (size_t i = 0; i < k; i++) write_identity(pts[i]->group, out[i]);
+        return PS_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
+    if (c->forced_slice) pl.M = c->forced_slice;
+    int rc = msm_sort(c, sc, pl, false);
+    if (rc) return rc;
+    c->ev_valid = false;
+    for (size_t i = 0; i < k; i++) {
+        if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
+        rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(c, pts[i], sc->n, pl, false, (int)i)
+                                    : msm_points_t<Fp2>(c, pts[i], sc->n, pl, false, (int)i);
+        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
+        HIP_TRY(hipEventRecord(c->ev_multi[i], c->stream));
+    }
+    for (size_t i = 0; i < k; i++) {  // fold result i on the host while the GPU works on i+1...
+        HIP_TRY(hipEventSynchronize(c->ev_multi[i]));
+        if (pts[i]->group == PS_G1) msm_fold_host<Fp>(c, pl, (int)i, out[i]);
+        else msm_fold_host<Fp2>(c, pl, (int)i, out[i]);
+    }
+    u32 entries = *(u32*)((char*)c->h_pinned + c->h_pinned_cap - 8);
+    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    return PS_OK;
 }
 
 extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* sc) {
@@ -606,7 +679,7 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
     }
     MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
     if (c->forced_slice) pl.M = c->forced_slice;
-    int rc = pts->group == PS_G1 ? msm_launch_t<Fp>(c, pts, sc, pl) : msm_launch_t<Fp2>(c, pts, sc, pl);
+    int rc = msm_launch_any(c, pts, sc, pl);
     if (rc) return rc;
     c->pending = true;
     c->pending_group = pts->group;
@@ -619,15 +692,14 @@ extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
     if (!c->pending) return fail(PS_ERR_ARG, "ps_msm_finish: nothing pending");
     c->pending = false;
     const MsmPlan& pl = c->pending_plan;
-    if (pl.W == 0) {  // empty sum: the identity (zero.Clone(), algebra.go:353)
-        memset(out, 0, wire_bytes(c->pending_group));
-        out[0] = 0x40;
+    if (pl.W == 0) {  // empty sum: the identity
+        write_identity(c->pending_group, out);
         return PS_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->pending_group == PS_G1) msm_fold_host<Fp>(c, pl, out);
-    else msm_fold_host<Fp2>(c, pl, out);
+    if (c->pending_group == PS_G1) msm_fold_host<Fp>(c, pl, 0, out);
+    else msm_fold_host<Fp2>(c, pl, 0, out);
     u32 entries = *(u32*)((char*)c->h_pinned + c->h_pinned_cap - 8);
     c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
     return PS_OK;

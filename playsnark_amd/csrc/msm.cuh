@@ -39,8 +39,11 @@ struct MsmPlan {
 static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     MsmPlan best{};
     double best_cost = 1e300;
-    for (int c = 4; c <= 20; c++) {  // c >= 4 keeps W <= 64
-        if (forced_c && c != forced_c) continue;
+    // c >= 4 keeps W <= 64.  Above c = 16 the bucket array (W * 2^(c-1) XYZZ points of 224 / 448 B) no
+    // longer fits the 256 MB infinity cache and the sort scatters over too wide a range: measured at
+    // 2^22 and 2^24 points, c = 16 beats 17..20 although the model below prefers them.
+    for (int c = 4; c <= 20; c++) {
+        if (forced_c ? c != forced_c : c > 16) continue;
         int W = max_bits / c + 1;
         double nb = (double)(1u << (c - 1));
         double cost = (double)n * W * 10.0 + W * nb * 42.0;
@@ -52,7 +55,12 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     }
     best.NB = 1u << (best.c - 1);
     best.G = (u64)best.W * best.NB;
+    // entries per accumulation thread: 32 keeps ~2^19 threads busy at 2^20 points; larger inputs get
+    // longer slices (same thread count), so a bucket of n / 2^(c-1) entries still spans only a few
+    // slices and the fix-up chains stay short
     best.M = 32;
+    const u64 total = (u64)n * best.W;
+    while (best.M < 1024 && total / (2 * (u64)best.M) >= (1u << 19)) best.M *= 2;
     best.SEG = 8;
     return best;
 }
@@ -165,21 +173,24 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
         u32 key = 0xffffffffu, val = 0, rank = 0;
         const bool act = p < total;
         if (act) { key = (u32)w * NB + lkey[p]; val = lval[p]; }
-        // lanes that share the first active lane's bucket are served by one atomic of their count
-        const unsigned long long active = __ballot(act);
+        // lanes that share a bucket are served by one atomic of their count: up to 8 rounds, each
+        // serving the group of the first unserved lane (narrow top windows and skewed witnesses put a
+        // whole wave into a handful of buckets); what is left goes one atomic per lane
         bool done = !act;
-        if (active) {
-            const int leader = __ffsll((long long)active) - 1;
+        for (int round = 0; round < 8; round++) {
+            const unsigned long long pending = __ballot(!done);
+            if (!pending) break;
+            const int leader = __ffsll((long long)pending) - 1;
             const u32 lk = __shfl(key, leader, 64);
-            const unsigned long long same = __ballot(act && key == lk);
-            if (__popcll(same) > 1) {
-                u32 b0 = 0;
-                if ((int)(tid & 63) == leader) b0 = atomicAdd(&counts[lk], (u32)__popcll(same));
-                b0 = __shfl(b0, leader, 64);
-                if (act && key == lk) {
-                    rank = b0 + (u32)__popcll(same & ((1ull << (tid & 63)) - 1ull));
-                    done = true;
-                }
+            const bool mine = !done && key == lk;
+            const unsigned long long same = __ballot(mine);
+            if (__popcll(same) == 1) break;  // nothing to share
+            u32 b0 = 0;
+            if ((int)(tid & 63) == leader) b0 = atomicAdd(&counts[lk], (u32)__popcll(same));
+            b0 = __shfl(b0, leader, 64);
+            if (mine) {
+                rank = b0 + (u32)__popcll(same & ((1ull << (tid & 63)) - 1ull));
+                done = true;
             }
         }
         if (!done) rank = atomicAdd(&counts[key], 1u);
@@ -760,6 +771,24 @@ __global__ void __launch_bounds__(256) k_fixed_base_table(Affine<F>* __restrict_
     Affine<F> out;
     if (!xyzz_to_affine<F>(acc, out.x, out.y)) { out.x = f_zero((const F*)0); out.y = f_zero((const F*)0); }
     table[idx] = out;
+}
+
+// out[i] = a[i] + b[i] + c[i] (affine in, affine out; (0,0) is the identity)
+template <class F>
+__global__ void __launch_bounds__(256, 2) k_points_add3(const Affine<F>* __restrict__ a, const Affine<F>* __restrict__ b,
+                                                        const Affine<F>* __restrict__ c3, u32 n, Affine<F>* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xyzz<F> acc = xyzz_identity<F>();
+    const Affine<F>* src[3] = {a, b, c3};
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) {
+        Affine<F> t = src[k][i];
+        if (!(f_is_zero(t.x) && f_is_zero(t.y))) xyzz_madd<F>(acc, t.x, t.y);
+    }
+    Affine<F> r;
+    if (!xyzz_to_affine<F>(acc, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
+    out[i] = r;
 }
 
 template <class F>

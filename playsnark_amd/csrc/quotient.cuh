@@ -258,6 +258,11 @@ __global__ void __launch_bounds__(256) k_linear_poly(Fr* __restrict__ out, const
     Fr lp = fr_norm(fr_add(fr_add(fr_mul(beta, u[i]), fr_mul(alpha, v[i])), w[i]));
     out[i] = fr_mul(lp, i < diff ? ginv : dinv);
 }
+// out[i] = scale * in[i]   (generateEvalCommit's `Mul(p.Eval(s), shift)`, pinochio.go:381-388)
+__global__ void __launch_bounds__(256) k_fr_scale(Fr* __restrict__ out, const Fr* __restrict__ in, Fr scale, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = fr_mul(in[i], scale);
+}
 __global__ void __launch_bounds__(64) k_set_one(Fr* __restrict__ p, u64 idx) {
     if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = fr_one();
 }

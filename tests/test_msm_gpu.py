@@ -210,3 +210,33 @@ def test_compressed_upload_decompresses_on_the_gpu(ps_api, ctx, co, pr, name):
     with pytest.raises(ps_api.PlaysnarkError) as e:
         ps_api.Points.upload(ctx, gid, bytes(bad), fmt=ps_api.FMT_COMPRESSED)
     assert e.value.code == -3
+
+
+@pytest.mark.parametrize("n", [0, 1, 77, 3000])
+def test_msm_multi_shares_one_sort(ps_api, ctx, co, pr, n):
+    """ps_msm_multi: several point arrays (G1 and G2 mixed) against ONE scalar vector -- the shape of
+    the nine computeSolCommit calls (pinochio.go:231-241) -- equals one BlindEval per array and the
+    oracle's sums; a wrong-length array is the reference's length panic (algebra.go:350-352)."""
+    rng = _rng(pr, 7000 + n)
+    sc = [rng.fr() for _ in range(n)]
+    if n > 4:
+        sc[1], sc[2], sc[3] = 0, pr.R - 1, sc[4]
+    kinds = ["g1", "g2", "g1", "g1"]
+    raws, pts = [], []
+    for j, name in enumerate(kinds):
+        gid, og = _grp(ps_api, co, name)
+        raw = og.gen_points(rng.fr(), rng.fr(), n)
+        if n > 4 and j == 2:  # identity points and a repeated point inside one array
+            raw = og.to_b(None) + raw[og.nb : 2 * og.nb] * 2 + raw[3 * og.nb :]
+        raws.append(raw)
+        pts.append(ps_api.Points.upload(ctx, gid, raw))
+    dsc = ps_api.Poly.upload(ctx, sc)
+    got = ps_api.msm_multi(ctx, pts, dsc)
+    for name, raw, p, g in zip(kinds, raws, pts, got):
+        og = _grp(ps_api, co, name)[1]
+        assert g == dsc.BlindEval(p)
+        want = og.blind_eval(sc, raw) if n <= 64 else og.msm_pippenger(co.pack_fr(sc), raw, n, 4)
+        assert g == og.to_b(want)
+    if n:
+        with pytest.raises(ps_api.LengthMismatch):
+            ps_api.msm_multi(ctx, [pts[0], pts[0].slice(0, n - 1)], dsc)

@@ -215,3 +215,46 @@ def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     # x on the interpolation domain is refused (a Lagrange denominator would vanish)
     with pytest.raises(ps_api.PlaysnarkError):
         ps_api.NewGroth16TrustedSetup(q, tox[0], tox[1], tox[2], 3, tox[4])
+
+
+@pytest.mark.parametrize("n", [4, 37, 200])
+def test_phgr13_trusted_setup_on_device(ps_api, ctx, co, pr, n):
+    """NewPHGR13TrustedSetup (pinochio.go:93-176) on the device against the oracle: the ten
+    evaluation-key arrays, the seven fixed verification-key points and vk.vs / vk.ws / vk.ys over all
+    variables are byte-identical; a proof made with the device EK equals the oracle's proof and
+    PHGR13Verify (pinochio.go:281-378) accepts it with the device VK."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 93 + n)
+    if n == 4:
+        c, wit = rs.toy_circuit()
+        sol = [pr.fr(v) for v in wit]
+    else:
+        c, sol = rs.synthetic_circuit(n)
+    diff = c.nbVars - c.nbIO
+    tox = [rng.fr() for _ in range(8)]
+    want = rs.phgr13_setup(c, *tox)
+    q = _upload_circuit(ps_api, ctx, c)
+    ek, vk = ps_api.NewPHGR13TrustedSetup(q, *tox)
+    for f in ps_api.PHGR13EvalKey.FIELDS:
+        assert getattr(ek, f).download() == getattr(want.EK, f), f
+    G1, G2 = co.G1, co.G2
+    groups = {"av": G2, "aw": G1, "ay": G2, "gamma": G2, "bgamma": G1, "bgamma2": G2, "yts": G2}
+    for f, grp in groups.items():
+        assert getattr(vk, f) == grp.to_b(getattr(want.VK, f)), f
+    assert vk.vs.download() == G1.pack(want.VK.vs)
+    assert vk.ws.download() == G2.pack(want.VK.ws)
+    assert vk.ys.download() == G1.pack(want.VK.ys)
+    sol_dev = ps_api.Poly.upload(ctx, sol)
+    proof = ps_api.PHGR13Prove(ek, q, sol_dev)
+    ref = rs.phgr13_prove(want.EK, c, sol, fast=n > 16)
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(proof, f) == getattr(ref, f), f
+    io = ps_api.Poly.upload(ctx, sol[:diff])
+    args = (vk.vs.slice(0, diff), vk.ws.slice(0, diff), vk.ys.slice(0, diff))
+    assert ps_api.PHGR13Verify(ctx, vk.fixed_points(), *args, proof, io)
+    bad_io = list(sol[:diff])
+    bad_io[0] = (bad_io[0] + 1) % pr.R
+    assert not ps_api.PHGR13Verify(ctx, vk.fixed_points(), *args, proof, ps_api.Poly.upload(ctx, bad_io))
+    with pytest.raises(ps_api.PlaysnarkError):  # s on the interpolation domain
+        ps_api.NewPHGR13TrustedSetup(q, 2, *tox[1:])

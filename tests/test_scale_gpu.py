@@ -40,7 +40,6 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
 
     # ---- CRS on the device: NewGroth16TrustedSetup (groth16.go:64-101), toxic waste retained for the checks
     up = lambda vals: ps_api.Poly.upload(ctx, vals)
-    g1 = lambda vals: ps_api.Points.from_scalars(ctx, ps_api.G1, up(vals))
     one = lambda grp, k: grp.to_b(grp.mul(k))
     t0 = time.time()
     q = ps_api.QAP(ctx, m, c.nbIO, c.left, c.right, c.out)
@@ -92,9 +91,33 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     cd = (res + s * a + r * b - r * s % R * delta) % R
     assert proof.C == one(co.G1, cd)
 
-    # ---- PHGR13 on the same QAP: hs == h(s) G with the same h evaluated at a fresh point ----
-    sp = rng.fr()
-    gsi = g1(_powers(sp, n - 1, 1, R))
-    hs = ps_api.Poly.upload(ctx, h).BlindEval(gsi)
-    assert hs == one(co.G1, poly_eval_bytes(h, n - 1, sp))
+    # ---- PHGR13 on the same QAP (BASELINE config #5 shape): device setup, prove, discrete-log checks of
+    # every proof element from the retained toxic waste (pinocchio_test.go:33-146), pairing verification
+    tox = [rng.fr() for _ in range(8)]
+    sp, av, aw, ay, rv, rw, pbeta, pgamma = tox
+    del tr, vk, proof
+    t0 = time.time()
+    ek, pvk = ps_api.NewPHGR13TrustedSetup(q, *tox)
+    ctx.sync()
+    t["phgr13_device_setup_s"] = time.time() - t0
+    ps_api.PHGR13Prove(ek, q, dsol)  # warm-up
+    t0 = time.time()
+    pp = ps_api.PHGR13Prove(ek, q, dsol)
+    t["phgr13_prove_s"] = time.time() - t0
+    us, vs_, ws_, zs = rs.var_poly_evals(c, sp)
+    ry = rv * rw % R
+    dot = lambda ev: sum(e * si for e, si in zip(ev[diff:], sol[diff:])) % R
+    Vm, Wm, Ym = dot(us), dot(vs_), dot(ws_)
+    assert pp.hs == one(co.G1, poly_eval_bytes(h, n - 1, sp))
+    assert pp.vss == one(co.G1, rv * Vm % R) and pp.vass == one(co.G1, rv * av % R * Vm % R)
+    assert pp.wss == one(co.G2, rw * Wm % R) and pp.wass == one(co.G1, rw * aw % R * Wm % R)
+    assert pp.yss == one(co.G1, ry * Ym % R) and pp.yass == one(co.G1, ry * ay % R * Ym % R)
+    assert pp.gz == one(co.G1, pbeta * (rv * Vm + rw * Wm + ry * Ym) % R)
+    t0 = time.time()
+    io = up(sol[:diff])
+    io_arrays = (pvk.vs.slice(0, diff), pvk.ws.slice(0, diff), pvk.ys.slice(0, diff))
+    assert ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, pp, io)
+    t["phgr13_verify_s"] = time.time() - t0
+    pp.gz = one(co.G1, 12345)
+    assert not ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, pp, io)
     print("SCALE " + json.dumps({"log2n": log2n, "n_vars": m, **{k: round(val, 4) for k, val in t.items()}}))
