@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
+                    help="sums kept in flight per GPU (k: step i+k-1 is enqueued before step i is folded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="CPU baseline MSM size (default: the full workload)")
     args = ap.parse_args()
@@ -128,16 +130,25 @@ def main():
         ctx.sync()
 
     result = None
-    for _ in range(args.warmup):
-        result = msm.run(points, scalars)
-    ctx.set_timing(True)
-    stage_ms = {k: 0.0 for k in api.Context.STAGES}
+    if args.warmup:
+        result = msm.run_pipelined(points, scalars, max(args.warmup, args.in_flight), depth=args.in_flight)
+    # one-at-a-time latency, outside the timed region (reported beside the pipelined throughput)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = msm.run(points, scalars)
+    for _ in range(3):
+        msm.run(points, scalars)
+    barrier()
+    single_ms = (time.perf_counter() - t0) / 3 * 1e3
+    ctx.set_timing(True)
+    stage_ms = {k: 0.0 for k in api.Context.STAGES}
+
+    def add_stage_times():
         for k, v in ctx.last_stage_ms().items():
             stage_ms[k] += v
+
+    barrier()
+    t0 = time.perf_counter()
+    result = msm.run_pipelined(points, scalars, args.steps, add_stage_times, depth=args.in_flight)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -169,6 +180,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_one_at_a_time": single_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -179,6 +191,7 @@ def main():
                 "window_bits": c,
                 "windows": W,
                 "slice": info["slice"],
+                "in_flight": args.in_flight,
                 "sharding": "index range per rank, all_gather of 96-B partial sums" if world > 1 else "single GPU",
             },
             "g1_adds_per_s": adds * world * args.steps / elapsed,

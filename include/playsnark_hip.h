@@ -88,8 +88,13 @@ int ps_msm(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars, uint
 /* Host-buffer convenience forms (upload + ps_msm). */
 int ps_msm_be32(ps_ctx* ctx, const ps_points* points, const uint8_t* scalars_be32, size_t n, uint8_t* out);
 int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, size_t n, uint8_t* out);
-/* Asynchronous form for benchmarking and multi-MSM overlap: launches on the context stream and
- * leaves the per-window sums on the device; ps_msm_finish() waits and folds them on the host. */
+/* Asynchronous form: ps_msm_launch enqueues the sum and leaves the per-window sums on the device;
+ * ps_msm_finish() waits for the OLDEST pending sum and folds it on the host.  Up to PS_MSM_QUEUE sums
+ * may be pending on a context (PS_ERR_ARG beyond that): each runs on its own internal stream and
+ * workspace, the accumulations chained in launch order, so a caller that keeps the queue full
+ * (launch i+2, then finish i) hides each sum's sort and its latency-bound tail -- bucket fix-up,
+ * reduction, host fold -- under its neighbours' accumulations. */
+#define PS_MSM_QUEUE 3
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);
 /* k sums over ONE scalar vector: out[i] = sum_j scalars[j] * points[i][j].  The digit sort runs once and
@@ -166,6 +171,12 @@ typedef struct { /* PHGR13Proof (pinochio.go:180-203) */
 /* PHGR13Prove (pinochio.go:207-254). */
 int ps_phgr13_prove(ps_ctx* ctx, const ps_phgr13_ek* ek, const ps_qap* q, const ps_scalars* sol,
                     ps_phgr13_proof* out);
+
+/* Host wall-clock split of the last ps_groth16_prove / ps_phgr13_prove on this context, in ms:
+ * [0] quotient h(x) (SpMV, gate check, interpolations, division), [1] scalar preparation (Groth16) or
+ * the h(s) sum (PHGR13), [2] the remaining sums incl. host folds, [3] total.  For reports only. */
+#define PS_PROVE_PHASES 4
+int ps_prove_last_phase_ms(ps_ctx* ctx, float ms[PS_PROVE_PHASES]);
 
 /* ---- trusted setup on the device ---- */
 typedef struct { uint8_t alpha[32], beta[32], delta[32], x[32], gamma[32]; } ps_groth16_toxic; /* groth16.go:15-26 */

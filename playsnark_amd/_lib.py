@@ -28,8 +28,11 @@ SYMBOLS = [
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
-    "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal",
+    "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
 ]
+
+
+PS_MSM_QUEUE = 3  # pending sums per context (include/playsnark_hip.h)
 
 
 class MsmInfo(C.Structure):
@@ -150,6 +153,7 @@ def _load():
     lib.ps_phgr13_setup.argtypes = [vp, vp, C.POINTER(Phgr13Toxic), C.POINTER(Phgr13Crs)]
     lib.ps_phgr13_crs_free.argtypes = [C.POINTER(Phgr13Crs)]
     lib.ps_phgr13_crs_free.restype = None
+    lib.ps_prove_last_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ps_groth16_verify.argtypes = [vp, C.POINTER(Groth16Vk), vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
     lib.ps_phgr13_verify.argtypes = [vp, C.POINTER(Phgr13Vk), vp, C.POINTER(Phgr13Proof), C.POINTER(C.c_int)]
     lib.ps_pairing_equal.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]

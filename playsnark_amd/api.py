@@ -85,6 +85,12 @@ class Context:
         _check(lib.ps_msm_last_stage_ms(self._h, ms))
         return dict(zip(self.STAGES, list(ms)))
 
+    def last_prove_phase_ms(self) -> dict:
+        """Host wall-clock split of the last Groth16Prove / PHGR13Prove on this context."""
+        ms = (C.c_float * 4)()
+        _check(lib.ps_prove_last_phase_ms(self._h, ms))
+        return dict(zip(("quotient", "prep_or_h_sum", "sums", "total"), list(ms)))
+
     def last_msm_info(self) -> dict:
         info = _lib.MsmInfo()
         _check(lib.ps_msm_last_info(self._h, C.byref(info)))

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -67,6 +68,12 @@ constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>);  // window sums of one
 struct ps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // The latency-bound tail of a sum (fix-up, reduction, copy of the window sums) runs on its own
+    // high-priority stream: when it shares the chip with another sum's accumulation, its few
+    // workgroups are dispatched ahead of the thousands the accumulation has queued.
+    hipStream_t tail = nullptr;
+    hipEvent_t ev_acc_local = nullptr, ev_tail_done = nullptr;
+    bool tail_used = false;
     // MSM workspace
     DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy;
     DevBuf staging;                  // byte staging for uploads / downloads
@@ -75,10 +82,19 @@ struct ps_ctx {
     u32* d_flag = nullptr;           // small device scratch word (bad-point counter etc.)
     void* h_pinned = nullptr;        // pinned host scratch for window sums
     size_t h_pinned_cap = 0;
-    // pending async MSM
-    bool pending = false;
-    int pending_group = 0;
-    MsmPlan pending_plan{};
+    // asynchronous sums: a FIFO of at most PS_MSM_QUEUE (ps_msm_launch, ..., then ps_msm_finish pops
+    // the oldest).  Each pending sum has its own workspace (the context itself, then `pipe`, `pipe2`:
+    // own streams + buffers); accumulations are chained in launch order, so a later sum's sort and
+    // accumulation run beside the earlier ones' latency-bound fix-up / reduction / host fold.
+    struct PendingMsm { int group; MsmPlan plan; ps_ctx* wc; };
+    PendingMsm q[PS_MSM_QUEUE];
+    int q_head = 0, q_len = 0;
+    bool pending = false;            // q_len > 0
+    ps_ctx *pipe = nullptr, *pipe2 = nullptr;
+    hipEvent_t ev_fork = nullptr;
+    ps_ctx* last_chain = nullptr;    // workspace of the sum launched last (its ev_acc_local = accumulation done)
+    ps_ctx* last_timed = nullptr;
+    float phase_ms[PS_PROVE_PHASES] = {0, 0, 0, 0};  // host wall clock of the last prover call
     ps_msm_info last_info{};
     int forced_c = 0;
     int forced_slice = 0;
@@ -98,6 +114,8 @@ struct ps_ctx {
     hipEvent_t ev[PS_MSM_STAGES + 1] = {};
     bool ev_valid = false;
     hipEvent_t ev_multi[PS_MSM_MULTI_MAX] = {};  // one per result of ps_msm_multi (created on first use)
+    hipEvent_t ev_acc[PS_MSM_MULTI_MAX] = {};    // ... and one per accumulation kernel
+    hipEvent_t ev_sorted = nullptr;
 };
 
 struct Storage {  // shared device allocation behind slices
@@ -155,6 +173,13 @@ extern "C" int ps_ctx_create(int device, ps_ctx** out) {
     ps_ctx* c = new ps_ctx();
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&c->tail, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_acc_local, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
+    }
     HIP_TRY(hipMalloc((void**)&c->d_flag, 64));
     c->h_pinned_cap = PS_MSM_MULTI_MAX * PS_PINNED_SLOT + 64;
     HIP_TRY(hipHostMalloc(&c->h_pinned, c->h_pinned_cap));
@@ -167,6 +192,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->tail) (void)hipStreamSynchronize(c->tail);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
                       &c->segs, &c->wins, &c->heavy, &c->vals, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
@@ -177,10 +203,18 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (c->g16_ready) (void)hipEventDestroy(c->g16_ready);
     if (c->phgr_bsum) ps_points_free(c->phgr_bsum);
     if (c->aux) ps_ctx_destroy(c->aux);
+    if (c->pipe) ps_ctx_destroy(c->pipe);
+    if (c->pipe2) ps_ctx_destroy(c->pipe2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_multi) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_acc) if (e) (void)hipEventDestroy(e);
+    if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev_acc_local) (void)hipEventDestroy(c->ev_acc_local);
+    if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
+    if (c->tail) (void)hipStreamDestroy(c->tail);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -189,6 +223,7 @@ extern "C" int ps_ctx_sync(ps_ctx* c) {
     if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->tail));
     return PS_OK;
 }
 extern "C" void* ps_ctx_stream(ps_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -518,6 +553,7 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     if ((rc = c->vals.ensure(4 * total))) return rc;
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
     hipStream_t st = c->stream;
+    if (c->tail_used) HIP_TRY(hipStreamWaitEvent(st, c->ev_tail_done, 0));  // the last tail still reads offs
     int evi = 0;
     PS_STAGE_MARK();  // 0: start
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
@@ -549,9 +585,14 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     return PS_OK;
 }
 
-// window sums of one point array over the sorted entries, copied to pinned slot `slot`
+// Window sums of one point array over the sorted entries of `c`, copied to pinned slot `slot` of `c`.
+// The work buffers and the stream are those of `wc` (c itself, or c->aux when ps_msm_multi
+// alternates two workspaces so that the latency-bound tail of one sum -- fix-up and reduction, ~1.3 ms
+// of short dependency chains on a mostly idle chip -- runs under the next sum's accumulation).
+// wait_acc: event the accumulation waits for; acc_done: recorded right after it.
 template <class F>
-static int msm_points_t(ps_ctx* c, const ps_points* pts, size_t n, const MsmPlan& pl, bool timed, int slot) {
+static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, const MsmPlan& pl, bool timed, int slot,
+                        hipEvent_t wait_acc, hipEvent_t acc_done) {
     typedef typename KernelField<F>::type KF;      // Fp -> Fp, Fp2 -> lane-split Fp2s
     constexpr unsigned LN = FieldTraits<KF>::LANES;  // lanes per logical thread
     const u64 total = (u64)pl.W * n;
@@ -562,51 +603,61 @@ static int msm_points_t(ps_ctx* c, const ps_points* pts, size_t n, const MsmPlan
     const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
     const u32 l2_jobs = (u32)pl.W * (u32)(red_bits + 1);
     int rc;
-    if ((rc = c->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
-    if ((rc = c->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
-    if ((rc = c->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
-    if ((rc = c->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
+    if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
+    if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
+    if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
+    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
-    if ((rc = c->heavy.ensure(4 * (max_heavy + 1)))) return rc;
+    if ((rc = wc->heavy.ensure(4 * (max_heavy + 1)))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
-    hipStream_t st = c->stream;
+    hipStream_t st = wc->stream;
     int evi = 4;
-    HIP_TRY(hipMemsetAsync(c->heavy.p, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(c->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
+    if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
+    HIP_TRY(hipMemsetAsync(wc->heavy.p, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
+    if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
     hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
-                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)c->buckets.p,
-                       (Xyzz<F>*)c->parts.p);
+                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)wc->buckets.p,
+                       (Xyzz<F>*)wc->parts.p);
+    if (acc_done) HIP_TRY(hipEventRecord(acc_done, st));
     PS_STAGE_MARK();  // 4: after accumulate
+    HIP_TRY(hipEventRecord(wc->ev_acc_local, st));
+    st = wc->tail;  // ---- the rest runs on the high-priority tail stream ----
+    HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
     hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
-                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (u32*)c->heavy.p, (u32*)c->heavy.p + 1);
+                       (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
-                       (const Xyzz<F>*)c->parts.p, (Xyzz<F>*)c->buckets.p, (const u32*)c->heavy.p,
-                       (const u32*)c->heavy.p + 1);
+                       (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (const u32*)wc->heavy.p,
+                       (const u32*)wc->heavy.p + 1);
     PS_STAGE_MARK();  // 5: after fixup
     {
-        Xyzz<F>* accs = (Xyzz<F>*)c->segs.p;
+        Xyzz<F>* accs = (Xyzz<F>*)wc->segs.p;
         Xyzz<F>* runs = accs + nseg_total;
         Xyzz<F>* l2 = runs + nseg_total;
-        hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)c->buckets.p,
+        hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
                            nseg_total, accs, runs);
         hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
                            (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
         hipLaunchKernelGGL(k_reduce_l3<KF>, dim3(1), dim3(128), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
-                           (Xyzz<F>*)c->wins.p);
+                           (Xyzz<F>*)wc->wins.p);
     }
     PS_STAGE_MARK();  // 6: after reduction
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, c->wins.p, sizeof(Xyzz<F>) * pl.W,
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * pl.W,
                            hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(wc->ev_tail_done, st));
+    wc->tail_used = true;
     return PS_OK;
 }
 #undef PS_STAGE_MARK
 
-static int msm_launch_any(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl) {
-    int rc = msm_sort(c, sc, pl, c->timing);
+static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl, hipEvent_t wait_acc,
+                          hipEvent_t acc_done) {
+    int rc = msm_sort(wc, sc, pl, wc->timing);
     if (rc) return rc;
-    rc = pts->group == PS_G1 ? msm_points_t<Fp>(c, pts, sc->n, pl, c->timing, 0) : msm_points_t<Fp2>(c, pts, sc->n, pl, c->timing, 0);
-    c->ev_valid = c->timing && !rc;
+    rc = pts->group == PS_G1 ? msm_points_t<Fp>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done)
+                             : msm_points_t<Fp2>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done);
+    wc->ev_valid = wc->timing && !rc;
     return rc;
 }
 
@@ -626,16 +677,70 @@ static void write_identity(int group, uint8_t* out) {  // zero.Clone(), algebra.
     out[0] = 0x40;
 }
 
-extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, const ps_scalars* sc, uint8_t* const* out) {
-    if (!c || !pts || !sc || !out) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
-    if (k == 0) return PS_OK;
-    if (k > PS_MSM_MULTI_MAX) return fail(PS_ERR_ARG, "ps_msm_multi: more than PS_MSM_MULTI_MAX point arrays");
+// k sums over one scalar vector.  The sort runs on w0's stream; the point passes alternate between the
+// workspaces w0 and w1 (w1 may equal w0 when k == 1), accumulation i+1 chained behind accumulation i
+// so that it runs beside the fix-up and reduction of sum i.  Events live on `c`.
+static int msm_multi_launch(ps_ctx* c, ps_ctx* w0, ps_ctx* w1, const ps_points* const* pts, size_t k, const ps_scalars* sc,
+                            const MsmPlan& pl) {
+    int rc;
+    if (w0 != c) {  // inputs prepared on the context stream are visible to the worker streams
+        if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(w0->stream, c->ev_fork, 0));
+    }
+    if ((rc = msm_sort(w0, sc, pl, false))) return rc;
+    w0->ev_valid = false;
+    if (!c->ev_sorted) HIP_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->ev_sorted, w0->stream));
+    if (w1 != w0) HIP_TRY(hipStreamWaitEvent(w1->stream, c->ev_sorted, 0));
     for (size_t i = 0; i < k; i++) {
-        if (!pts[i] || !out[i]) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
+        if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
+        if (!c->ev_acc[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming));
+        ps_ctx* wc = (i & 1) ? w1 : w0;
+        hipEvent_t wait = i ? c->ev_acc[i - 1] : nullptr;
+        rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i])
+                                    : msm_points_t<Fp2>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i]);
+        if (rc) {
+            (void)ps_ctx_sync(w0);
+            (void)ps_ctx_sync(w1);
+            return rc;
+        }
+        HIP_TRY(hipEventRecord(c->ev_multi[i], wc->tail));
+    }
+    return PS_OK;
+}
+
+// fold result i on the host while the GPU works on i+1...; out == nullptr just drains
+static int msm_multi_finish(ps_ctx* c, ps_ctx* w0, const ps_points* const* pts, size_t k, const MsmPlan& pl, uint8_t* const* out) {
+    for (size_t i = 0; i < k; i++) {
+        HIP_TRY(hipEventSynchronize(c->ev_multi[i]));
+        if (!out) continue;
+        if (pts[i]->group == PS_G1) msm_fold_host<Fp>(w0, pl, (int)i, out[i]);
+        else msm_fold_host<Fp2>(w0, pl, (int)i, out[i]);
+    }
+    u32 entries = *(u32*)((char*)w0->h_pinned + w0->h_pinned_cap - 8);
+    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    return PS_OK;
+}
+
+static int msm_multi_check(const char* who, const ps_points* const* pts, size_t k, const ps_scalars* sc) {
+    if (k > PS_MSM_MULTI_MAX) return fail(PS_ERR_ARG, std::string(who) + ": more than PS_MSM_MULTI_MAX point arrays");
+    for (size_t i = 0; i < k; i++) {
+        if (!pts[i]) return fail(PS_ERR_ARG, std::string(who) + ": NULL argument");
         if (pts[i]->n != sc->n)  // algebra.go:350-352
             return fail(PS_ERR_LENGTH, "mismatch of length between poly " + std::to_string(sc->n) + " and blinded eval points " +
                                            std::to_string(pts[i]->n));
     }
+    return PS_OK;
+}
+
+extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, const ps_scalars* sc, uint8_t* const* out) {
+    if (!c || !pts || !sc || !out) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
+    if (k == 0) return PS_OK;
+    int rc = msm_multi_check("ps_msm_multi", pts, k, sc);
+    if (rc) return rc;
+    for (size_t i = 0; i < k; i++)
+        if (!out[i]) return fail(PS_ERR_ARG, "ps_msm_multi: NULL argument");
     if (c->pending) return fail(PS_ERR_ARG, "ps_msm_multi: an MSM is already pending on this context");
     if (sc->n == 0) {
         for (size_t i = 0; i < k; i++) write_identity(pts[i]->group, out[i]);
@@ -644,24 +749,10 @@ extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, co
     HIP_TRY(hipSetDevice(c->device));
     MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
     if (c->forced_slice) pl.M = c->forced_slice;
-    int rc = msm_sort(c, sc, pl, false);
-    if (rc) return rc;
-    c->ev_valid = false;
-    for (size_t i = 0; i < k; i++) {
-        if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
-        rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(c, pts[i], sc->n, pl, false, (int)i)
-                                    : msm_points_t<Fp2>(c, pts[i], sc->n, pl, false, (int)i);
-        if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
-        HIP_TRY(hipEventRecord(c->ev_multi[i], c->stream));
-    }
-    for (size_t i = 0; i < k; i++) {  // fold result i on the host while the GPU works on i+1...
-        HIP_TRY(hipEventSynchronize(c->ev_multi[i]));
-        if (pts[i]->group == PS_G1) msm_fold_host<Fp>(c, pl, (int)i, out[i]);
-        else msm_fold_host<Fp2>(c, pl, (int)i, out[i]);
-    }
-    u32 entries = *(u32*)((char*)c->h_pinned + c->h_pinned_cap - 8);
-    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
-    return PS_OK;
+    if (k > 1 && !c->aux && (rc = ps_ctx_create(c->device, &c->aux))) return rc;
+    if (c->aux && c->aux->pending) return fail(PS_ERR_ARG, "ps_msm_multi: the auxiliary context is busy");
+    if ((rc = msm_multi_launch(c, c, k > 1 ? c->aux : c, pts, k, sc, pl))) return rc;
+    return msm_multi_finish(c, c, pts, k, pl, out);
 }
 
 extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* sc) {
@@ -669,39 +760,70 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
     if (pts->n != sc->n)  // algebra.go:350-352
         return fail(PS_ERR_LENGTH, "mismatch of length between poly " + std::to_string(sc->n) + " and blinded eval points " +
                                        std::to_string(pts->n));
-    if (c->pending) return fail(PS_ERR_ARG, "ps_msm_launch: an MSM is already pending on this context");
+    if (c->q_len == PS_MSM_QUEUE) return fail(PS_ERR_ARG, "ps_msm_launch: PS_MSM_QUEUE sums are already pending on this context");
     HIP_TRY(hipSetDevice(c->device));
-    if (sc->n == 0) {
-        c->pending = true;
-        c->pending_group = pts->group;
-        c->pending_plan = MsmPlan{};
-        return PS_OK;
+    // a workspace no pending sum is using: the context itself first
+    ps_ctx** slots[3] = {nullptr, &c->pipe, &c->pipe2};
+    ps_ctx* wc = nullptr;
+    for (int w = 0; w < 3 && !wc; w++) {
+        ps_ctx* cand = w == 0 ? c : *slots[w];
+        bool busy = false;
+        for (int j = 0; j < c->q_len; j++) busy = busy || (cand && c->q[(c->q_head + j) % PS_MSM_QUEUE].wc == cand);
+        if (busy) continue;
+        if (!cand) {
+            int rc = ps_ctx_create(c->device, slots[w]);
+            if (rc) return rc;
+            cand = *slots[w];
+        }
+        wc = cand;
     }
-    MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
-    if (c->forced_slice) pl.M = c->forced_slice;
-    int rc = msm_launch_any(c, pts, sc, pl);
-    if (rc) return rc;
+    if (wc != c) {
+        wc->timing = c->timing;
+        wc->forced_c = c->forced_c;
+        wc->forced_slice = c->forced_slice;
+    }
+    ps_ctx::PendingMsm& e = c->q[(c->q_head + c->q_len) % PS_MSM_QUEUE];
+    if (sc->n == 0) {
+        e = {pts->group, MsmPlan{}, wc};
+    } else {
+        MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
+        if (c->forced_slice) pl.M = c->forced_slice;
+        if (wc != c) {  // inputs prepared on the context stream are visible to the worker stream
+            if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
+        }
+        // chain the accumulations: this one starts when the previously launched one is done
+        hipEvent_t wait = (c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
+        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr);
+        if (rc) return rc;
+        c->last_chain = wc;
+        e = {pts->group, pl, wc};
+    }
+    c->q_len++;
     c->pending = true;
-    c->pending_group = pts->group;
-    c->pending_plan = pl;
     return PS_OK;
 }
 
 extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
     if (!c || !out) return fail(PS_ERR_ARG, "ps_msm_finish: NULL argument");
-    if (!c->pending) return fail(PS_ERR_ARG, "ps_msm_finish: nothing pending");
-    c->pending = false;
-    const MsmPlan& pl = c->pending_plan;
+    if (c->q_len == 0) return fail(PS_ERR_ARG, "ps_msm_finish: nothing pending");
+    const ps_ctx::PendingMsm e = c->q[c->q_head];
+    c->q_head = (c->q_head + 1) % PS_MSM_QUEUE;
+    c->q_len--;
+    c->pending = c->q_len > 0;
+    const MsmPlan& pl = e.plan;
     if (pl.W == 0) {  // empty sum: the identity
-        write_identity(c->pending_group, out);
+        write_identity(e.group, out);
         return PS_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->pending_group == PS_G1) msm_fold_host<Fp>(c, pl, 0, out);
-    else msm_fold_host<Fp2>(c, pl, 0, out);
-    u32 entries = *(u32*)((char*)c->h_pinned + c->h_pinned_cap - 8);
+    HIP_TRY(hipStreamSynchronize(e.wc->tail));  // ordered after everything the sum put on wc->stream
+    if (e.group == PS_G1) msm_fold_host<Fp>(e.wc, pl, 0, out);
+    else msm_fold_host<Fp2>(e.wc, pl, 0, out);
+    u32 entries = *(u32*)((char*)e.wc->h_pinned + e.wc->h_pinned_cap - 8);
     c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    c->last_timed = e.wc;
     return PS_OK;
 }
 
@@ -740,14 +862,22 @@ extern "C" int ps_ctx_set_timing(ps_ctx* c, int enable) {
     if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
     c->timing = enable != 0;
     c->ev_valid = false;
+    for (ps_ctx* w : {c->pipe, c->pipe2})
+        if (w) { w->timing = c->timing; w->ev_valid = false; }
     return PS_OK;
 }
 extern "C" int ps_msm_last_stage_ms(ps_ctx* c, float* ms) {
     if (!c || !ms) return fail(PS_ERR_ARG, "NULL argument");
-    if (!c->ev_valid) return fail(PS_ERR_ARG, "no timed MSM on this context (ps_ctx_set_timing)");
+    const ps_ctx* t = c->last_timed ? c->last_timed : c;  // the workspace of the sum finished last
+    if (!t->ev_valid) return fail(PS_ERR_ARG, "no timed MSM on this context (ps_ctx_set_timing)");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipEventSynchronize(c->ev[PS_MSM_STAGES]));
-    for (int i = 0; i < PS_MSM_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    HIP_TRY(hipEventSynchronize(t->ev[PS_MSM_STAGES]));
+    for (int i = 0; i < PS_MSM_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], t->ev[i], t->ev[i + 1]));
+    return PS_OK;
+}
+extern "C" int ps_prove_last_phase_ms(ps_ctx* c, float* ms) {
+    if (!c || !ms) return fail(PS_ERR_ARG, "NULL argument");
+    for (int i = 0; i < PS_PROVE_PHASES; i++) ms[i] = c->phase_ms[i];
     return PS_OK;
 }
 extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {

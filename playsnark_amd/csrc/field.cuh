@@ -800,7 +800,10 @@ PS_INL Fr fr_mul(const Fr& a, const Fr& b) {
         for (int i = 0; i <= k; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fr_mod28(k - i);
-        m[k] = (i32)(((u32)acc * FR_INV28) & FP_MASK);
+        // r = 1 mod 2^28 (two-adicity 32), so -r^-1 = -1 mod 2^28 and the Montgomery digit is a negation,
+        // not a (quarter-rate) v_mul_lo_u32
+        static_assert(FR_INV28 == FP_MASK, "m = -acc mod 2^28 needs r = 1 mod 2^28");
+        m[k] = (i32)((0u - (u32)acc) & FP_MASK);
         acc += (i64)m[k] * (i64)fr_mod28(0);
         acc >>= 28;
     }

@@ -54,16 +54,17 @@ __device__ inline Fr fr_shfl(const Fr& v, int src) {
     return r;
 }
 
-// block b: N(x) = sum_{k=0..63} d[64b+k] * prod_{i=64b+1}^{64b+k} (x - i), in place.
-// Horner in the Newton basis: poly = poly*(x - (64b+k+1)) + d[64b+k], k = 63..0.
-__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64) {
+// block b: N(x) = sum_{k=0..63} d[64b+k] * prod_{i=64b+1}^{64b+k} (x - (off + i)), in place.
+// Horner in the Newton basis: poly = poly*(x - (off+64b+k+1)) + d[64b+k], k = 63..0.
+// off = 0 for the QAP domain {1..n}; off = n for the nodes n+1.. of the h-only path.
+__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nblocks64) return;
     const u64 base = 64ull * wave;
     const Fr mine = d[base + lane];
     Fr coef = fr_zero();
-    Fr c = fr_from_u64(base + 64);  // node of step k = 63
+    Fr c = fr_from_u64(off + base + 64);  // node of step k = 63
     const Fr one = fr_one();
     for (int k = 63; k >= 0; k--) {
         Fr up = fr_shfl_up1(coef);
@@ -76,14 +77,14 @@ __global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nbl
     d[base + lane] = coef;
 }
 
-// block b: lower 64 coefficients of prod_{i=64b+1}^{64b+64} (x - i)  (the x^64 term is implied)
-__global__ void __launch_bounds__(256) k_subproduct_base(Fr* __restrict__ out, u32 nblocks64) {
+// block b: lower 64 coefficients of prod_{i=64b+1}^{64b+64} (x - (off + i))  (the x^64 term is implied)
+__global__ void __launch_bounds__(256) k_subproduct_base(Fr* __restrict__ out, u32 nblocks64, u64 off) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nblocks64) return;
     const u64 base = 64ull * wave;
     Fr coef = lane == 0 ? fr_one() : fr_zero();
-    Fr c = fr_from_u64(base + 1);
+    Fr c = fr_from_u64(off + base + 1);
     const Fr one = fr_one();
     for (int k = 0; k < 64; k++) {
         Fr up = fr_shfl_up1(coef);
@@ -216,6 +217,35 @@ __global__ void __launch_bounds__(256) k_fr_lincomb_plain(u32* __restrict__ out,
 #pragma unroll
     for (int j = 0; j < 8; j++) out[8 * i + j] = w[j];
 }
+// ---- h-only path: values of A, B, C on the nodes n+1 .. 2n-1 by one convolution each ----
+// Lagrange on {1..n}: P(x) = z(x) * sum_j w_j / (x - j) with w_j = P(j) / z'(j),
+// z'(j) = (j-1)! (n-j)! (-1)^(n-j).  out[j-1] = w_j for j <= n, 0 up to `total`.
+__global__ void __launch_bounds__(256) k_lagrange_weights(Fr* __restrict__ out, const Fr* __restrict__ y,
+                                                          const Fr* __restrict__ invfact, u64 n, u64 total) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    if (j >= n) { out[j] = fr_zero(); return; }
+    Fr w = fr_mul(fr_mul(y[j], invfact[j]), invfact[n - 1 - j]);
+    out[j] = ((n - 1 - j) & 1) ? fr_neg(w) : w;
+}
+// out[d-1] = 1/d = (d-1)! / d!  for d = 1..cnt, 0 up to `total`
+__global__ void __launch_bounds__(256) k_reciprocals(Fr* __restrict__ out, const Fr* __restrict__ fact,
+                                                     const Fr* __restrict__ invfact, u64 cnt, u64 total) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    out[i] = i < cnt ? fr_mul(fact[i], invfact[i + 1]) : fr_zero();
+}
+// hv[i] = h(n+1+i) = z(n+1+i) * S_A * S_B - S_C with S_P = (w_P * recip)[n+1+i], i < n-1;
+// z(n+k) = (n+k-1)! / (k-1)!.  The S_* arrays hold the cyclic convolutions (S_P(k) at index n-2+k).
+__global__ void __launch_bounds__(256) k_h_values(Fr* __restrict__ hv, const Fr* __restrict__ SA, const Fr* __restrict__ SB,
+                                                  const Fr* __restrict__ SC, const Fr* __restrict__ fact,
+                                                  const Fr* __restrict__ invfact, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const u64 idx = n - 1 + i;
+    Fr zs = fr_mul(fact[n + i], invfact[i]);
+    hv[i] = fr_norm(fr_sub(fr_mul(fr_mul(zs, SA[idx]), SB[idx]), SC[idx]));
+}
 // ---- trusted-setup helpers ----
 struct FrPow2Table { Fr p[32]; };  // p[k] = x^(2^k)
 // out[i] = shift * x^i  (GeneratePowersCommit's exponents, algebra.go:371-384)
@@ -279,6 +309,13 @@ struct QapTables {
     Fr* z = nullptr;             // n+1 coefficients of prod (x - i), i = 1..n
     Fr* ghat = nullptr;          // NTT_{2^ph} of rev(z)^-1 mod x^(n-1)
     int ph = 0, pp = 0;          // log sizes of the division / product transforms
+    // h-only path: h is interpolated from its values on the nodes n+1 .. 2n-1
+    Fr* fact2 = nullptr;         // 2np: j!            (invfact above has 2np entries as well)
+    Fr* rhat = nullptr;          // 2np: NTT of 1/d, d = 1..2n-2
+    u64 np_h = 0;                // power of two >= max(64, n-1)
+    int lognp_h = 0;
+    Fr* vhat_h = nullptr;        // 2np_h: NTT of v (== vhat when np_h == np)
+    std::vector<Fr*> zhat_h;     // subproduct tree over the nodes n+1 .. n+np_h
     // work buffers
     Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
     std::vector<void*> owned;
@@ -297,29 +334,59 @@ static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
     return e;
 }
 
-// Newton coefficients (np of them, zero beyond the true length) -> monomial coefficients, in place
-static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, const QapTables& qt, Fr* data, Fr* scratch) {
-    const u64 np = qt.np;
-    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64));
-    for (int logs = 7; logs <= qt.lognp; logs++) {
+// Newton coefficients on the nodes off+1, off+2, .. (np of them, zero beyond the true length) -> monomial
+// coefficients, in place
+static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, u64 np, int lognp, const std::vector<Fr*>& zhat,
+                                            u64 off, Fr* data, Fr* scratch) {
+    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64), off);
+    for (int logs = 7; logs <= lognp; logs++) {
         hipLaunchKernelGGL(k_level_prepare, dim3(nblk(np)), dim3(256), 0, st, scratch, data, np, logs);
         QT_TRY(ntt_run<false>(tabs, st, scratch, np, logs));
-        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(np)), dim3(256), 0, st, scratch, scratch, qt.zhat[logs], np);
+        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(np)), dim3(256), 0, st, scratch, scratch, zhat[logs], np);
         QT_TRY(ntt_run<true>(tabs, st, scratch, np, logs));
         hipLaunchKernelGGL(k_level_combine, dim3(nblk(np)), dim3(256), 0, st, data, scratch, np, logs);
     }
     return hipGetLastError();
 }
 
+// values y[0..cnt) = f(off+1 .. off+cnt)  ->  monomial coefficients of the degree < cnt interpolant, in qt.data.
+// The divided differences of equally spaced nodes do not depend on `off`: d_k = sum_j (y_j / j!) (-1)^(k-j) / (k-j)!.
+static inline hipError_t interpolate_on_nodes(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y, u64 cnt,
+                                              u64 np, int lognp, const Fr* vhat, const std::vector<Fr*>& zhat, u64 off) {
+    hipLaunchKernelGGL(k_scale_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, y, qt.invfact, cnt, 2 * np);
+    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, lognp + 1));
+    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, qt.t1, vhat, 2 * np);
+    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, lognp + 1));
+    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(np)), dim3(256), 0, st, qt.data, qt.t1, cnt, np);
+    return newton_to_monomial(tabs, st, np, lognp, zhat, off, qt.data, qt.scratch);
+}
 // values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
 static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y) {
-    const u64 np = qt.np, n = qt.n;
-    hipLaunchKernelGGL(k_scale_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, y, qt.invfact, n, 2 * np);
-    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, qt.lognp + 1));
-    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, qt.t1, qt.vhat, 2 * np);
-    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, qt.lognp + 1));
-    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(np)), dim3(256), 0, st, qt.data, qt.t1, n, np);
-    return newton_to_monomial(tabs, st, qt, qt.data, qt.scratch);
+    return interpolate_on_nodes(tabs, st, qt, y, qt.n, qt.np, qt.lognp, qt.vhat, qt.zhat, 0);
+}
+
+// h alone (PHGR13Prove and QAP.Quotient need no A, B coefficients): with y_P = P(1..n),
+//   P(n+k) = z(n+k) * sum_j w_j^P / (n+k-j)        one cyclic convolution of length 2np per polynomial
+//   h(n+k) = z(n+k) S_A(k) S_B(k) - S_C(k)         k = 1..n-1 (z(n+k) != 0)
+// and h (degree <= n-2) is the interpolant of those n-1 values on the nodes n+1..2n-1: ONE values ->
+// monomial conversion instead of two plus a product and a division.  Same polynomial, bit for bit.
+static inline hipError_t quotient_h_only(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* yA, const Fr* yB,
+                                         const Fr* yC, Fr* h_out) {
+    const u64 n = qt.n, L = 2 * qt.np;
+    if (n < 2) return hipSuccess;
+    const Fr* ys[3] = {yA, yB, yC};
+    Fr* S[3] = {qt.t1, qt.pa, qt.pb};
+    for (int k = 0; k < 3; k++) {
+        hipLaunchKernelGGL(k_lagrange_weights, dim3(nblk(L)), dim3(256), 0, st, S[k], ys[k], qt.invfact, n, L);
+        QT_TRY(ntt_run<false>(tabs, st, S[k], L, qt.lognp + 1));
+        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(L)), dim3(256), 0, st, S[k], S[k], qt.rhat, L);
+        QT_TRY(ntt_run<true>(tabs, st, S[k], L, qt.lognp + 1));
+    }
+    Fr* hv = qt.scratch;
+    hipLaunchKernelGGL(k_h_values, dim3(nblk(n - 1)), dim3(256), 0, st, hv, (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2],
+                       (const Fr*)qt.fact2, (const Fr*)qt.invfact, n);
+    QT_TRY(interpolate_on_nodes(tabs, st, qt, hv, n - 1, qt.np_h, qt.lognp_h, qt.vhat_h, qt.zhat_h, n));
+    return hipMemcpyAsync(h_out, qt.data, sizeof(Fr) * (n - 1), hipMemcpyDeviceToDevice, st);
 }
 
 // h = floor(A*B / z): n-1 coefficients into h_out (Montgomery); A, B have n coefficients
@@ -356,7 +423,9 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(ntt_tables_ensure(tabs, lg + 1, st));
     const u64 Sp = 1ull << qt.pp, Sh = 1ull << qt.ph;
     const u64 big = 2 * np > Sp ? 2 * np : Sp;
-    QT_TRY(qt_alloc(qt, &qt.invfact, np));
+    QT_TRY(qt_alloc(qt, &qt.invfact, 2 * np));
+    QT_TRY(qt_alloc(qt, &qt.fact2, 2 * np));
+    QT_TRY(qt_alloc(qt, &qt.rhat, 2 * np));
     QT_TRY(qt_alloc(qt, &qt.vhat, 2 * np));
     QT_TRY(qt_alloc(qt, &qt.t1, big));
     QT_TRY(qt_alloc(qt, &qt.data, np));
@@ -365,43 +434,67 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.pb, big));
     QT_TRY(qt_alloc(qt, &qt.z, n + 1));
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
-    // ---- factorials (host) ----
+    // ---- factorials up to 2np - 1 (host) ----
     {
-        std::vector<Fr> inv(np), v(np), fact(np);
+        const u64 nf = 2 * np;
+        std::vector<Fr> inv(nf), v(np), fact(nf);
         Fr f = fr_one();
-        for (u64 j = 0; j < np; j++) {
+        for (u64 j = 0; j < nf; j++) {
             if (j > 0) f = fr_mul(f, fr_from_u64(j));
             fact[j] = f;
         }
-        Fr finv = fr_inv(fact[np - 1]);
-        for (u64 j = np; j-- > 0;) {  // walk down: 1/(j-1)! = (1/j!) * j
+        Fr finv = fr_inv(fact[nf - 1]);
+        for (u64 j = nf; j-- > 0;) {  // walk down: 1/(j-1)! = (1/j!) * j
             inv[j] = finv;
             if (j > 0) finv = fr_mul(finv, fr_from_u64(j));
         }
         for (u64 j = 0; j < np; j++) v[j] = (j & 1) ? fr_neg(inv[j]) : inv[j];
-        QT_TRY(hipMemcpyAsync(qt.invfact, inv.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.invfact, inv.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.fact2, fact.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
         QT_TRY(hipMemcpyAsync(qt.t1, v.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
         QT_TRY(hipStreamSynchronize(st));
     }
     hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.vhat, qt.t1, np, 2 * np);
     QT_TRY(ntt_run<false>(tabs, st, qt.vhat, 2 * np, lg + 1));
-    // ---- subproduct tree ----
-    qt.zhat.assign(lg + 1, nullptr);
-    Fr *F = qt.data, *F2 = qt.scratch, *full = qt.t1;  // F: np, full: 2np, F2: np
-    hipLaunchKernelGGL(k_subproduct_base, dim3(nblk(np)), dim3(256), 0, st, F, (u32)(np / 64));
-    for (int logt = 6; logt < lg; logt++) {
-        const int log2t = logt + 1;
-        hipLaunchKernelGGL(k_tree_expand, dim3(nblk(2 * np)), dim3(256), 0, st, full, F, 2 * np, logt);
-        QT_TRY(ntt_run<false>(tabs, st, full, 2 * np, log2t));
-        Fr* zh;
-        QT_TRY(qt_alloc(qt, &zh, np));
-        qt.zhat[log2t] = zh;
-        hipLaunchKernelGGL(k_tree_take_left, dim3(nblk(np)), dim3(256), 0, st, zh, full, np, log2t);
-        hipLaunchKernelGGL(k_tree_pair_mul, dim3(nblk(np)), dim3(256), 0, st, F2, full, np, log2t);
-        QT_TRY(ntt_run<true>(tabs, st, F2, np, log2t));
-        hipLaunchKernelGGL(k_tree_fix, dim3(nblk(np >> log2t)), dim3(256), 0, st, F2, np >> log2t, log2t);
-        Fr* tmp = F; F = F2; F2 = tmp;
+    // h-only path: v again at the size of its own interpolation, and the reciprocals 1/d, d <= 2n-2
+    {
+        int lgh = ilog2_ceil(n - 1 < 64 ? 64 : n - 1);
+        qt.lognp_h = lgh;
+        qt.np_h = 1ull << lgh;
+        if (qt.np_h == np) {
+            qt.vhat_h = qt.vhat;
+        } else {
+            QT_TRY(qt_alloc(qt, &qt.vhat_h, 2 * qt.np_h));
+            hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(2 * qt.np_h)), dim3(256), 0, st, qt.vhat_h, qt.t1, qt.np_h, 2 * qt.np_h);
+            QT_TRY(ntt_run<false>(tabs, st, qt.vhat_h, 2 * qt.np_h, lgh + 1));
+        }
+        hipLaunchKernelGGL(k_reciprocals, dim3(nblk(2 * np)), dim3(256), 0, st, qt.rhat, (const Fr*)qt.fact2, (const Fr*)qt.invfact,
+                           n >= 2 ? 2 * n - 2 : (u64)0, 2 * np);
+        QT_TRY(ntt_run<false>(tabs, st, qt.rhat, 2 * np, lg + 1));
     }
+    // ---- subproduct trees: nodes 1..np (the QAP domain) and n+1..n+np_h (the h-only path) ----
+    Fr *F = qt.data, *F2 = qt.scratch, *full = qt.t1;  // F: np, full: 2np, F2: np
+    auto build_tree = [&](u64 tnp, int tlg, u64 off, std::vector<Fr*>& zhat) -> hipError_t {
+        zhat.assign(tlg + 1, nullptr);
+        F = qt.data; F2 = qt.scratch;
+        hipLaunchKernelGGL(k_subproduct_base, dim3(nblk(tnp)), dim3(256), 0, st, F, (u32)(tnp / 64), off);
+        for (int logt = 6; logt < tlg; logt++) {
+            const int log2t = logt + 1;
+            hipLaunchKernelGGL(k_tree_expand, dim3(nblk(2 * tnp)), dim3(256), 0, st, full, F, 2 * tnp, logt);
+            QT_TRY(ntt_run<false>(tabs, st, full, 2 * tnp, log2t));
+            Fr* zh;
+            QT_TRY(qt_alloc(qt, &zh, tnp));
+            zhat[log2t] = zh;
+            hipLaunchKernelGGL(k_tree_take_left, dim3(nblk(tnp)), dim3(256), 0, st, zh, full, tnp, log2t);
+            hipLaunchKernelGGL(k_tree_pair_mul, dim3(nblk(tnp)), dim3(256), 0, st, F2, full, tnp, log2t);
+            QT_TRY(ntt_run<true>(tabs, st, F2, tnp, log2t));
+            hipLaunchKernelGGL(k_tree_fix, dim3(nblk(tnp >> log2t)), dim3(256), 0, st, F2, tnp >> log2t, log2t);
+            Fr* tmp = F; F = F2; F2 = tmp;
+        }
+        return hipGetLastError();
+    };
+    if (n >= 2) QT_TRY(build_tree(qt.np_h, qt.lognp_h, n, qt.zhat_h));
+    QT_TRY(build_tree(np, lg, 0, qt.zhat));  // last: F holds the top node of the QAP domain
     // ---- z = prod_{i=1..n} (x - i) ----
     if (n == np) {  // F now holds the single top node: lower np coefficients, monic
         QT_TRY(hipMemcpyAsync(qt.z, F, sizeof(Fr) * n, hipMemcpyDeviceToDevice, st));
@@ -409,7 +502,7 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     } else {  // z is the Newton basis polynomial N_n: convert the unit vector e_n
         QT_TRY(hipMemsetAsync(qt.pa, 0, sizeof(Fr) * np, st));
         hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, qt.pa, n);
-        QT_TRY(newton_to_monomial(tabs, st, qt, qt.pa, qt.pb));
+        QT_TRY(newton_to_monomial(tabs, st, np, lg, qt.zhat, 0, qt.pa, qt.pb));
         QT_TRY(hipMemcpyAsync(qt.z, qt.pa, sizeof(Fr) * (n + 1), hipMemcpyDeviceToDevice, st));
     }
     // ---- g = rev(z)^-1 mod x^(n-1) by Newton iteration ----

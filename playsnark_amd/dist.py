@@ -44,3 +44,19 @@ class ShardedMsm:
         """Local MSM over this rank's shard, then the exchange."""
         api.msm_launch(self.ctx, points, scalars)
         return self.combine(api.msm_finish(self.ctx, self.group))
+
+    def run_pipelined(self, points: "api.Points", scalars: "api.Poly", steps: int, on_step=None, depth: int = 2) -> bytes:
+        """`steps` sums with up to `depth` in flight (ps_msm_launch ... / ps_msm_finish FIFO): later sums
+        are enqueued before the oldest is folded and exchanged, so their sort and accumulation run
+        beside its latency-bound tail.  Every sum is completed and combined; returns the last result."""
+        result = None
+        launched = finished = 0
+        while finished < steps:
+            while launched < steps and launched - finished < depth:
+                api.msm_launch(self.ctx, points, scalars)
+                launched += 1
+            result = self.combine(api.msm_finish(self.ctx, self.group))
+            finished += 1
+            if on_step:
+                on_step()
+        return result

@@ -240,3 +240,40 @@ def test_msm_multi_shares_one_sort(ps_api, ctx, co, pr, n):
     if n:
         with pytest.raises(ps_api.LengthMismatch):
             ps_api.msm_multi(ctx, [pts[0], pts[0].slice(0, n - 1)], dsc)
+
+
+def test_two_sums_in_flight_fifo(ps_api, ctx, co, pr):
+    """Up to PS_MSM_QUEUE sums pending on one context: results come back oldest first and equal the
+    one-at-a-time results (each pending sum has its own stream / workspace, accumulations chained in
+    launch order); a launch beyond the queue depth is refused; an empty sum may sit in the queue
+    (zero.Clone(), algebra.go:353)."""
+    rng = _rng(pr, 8800)
+    jobs = []
+    for gid, og, n in ((ps_api.G1, co.G1, 5000), (ps_api.G2, co.G2, 700), (ps_api.G1, co.G1, 0), (ps_api.G1, co.G1, 64)):
+        sc = [rng.fr() for _ in range(n)]
+        raw = og.gen_points(rng.fr(), rng.fr(), n)
+        pts, dsc = ps_api.Points.upload(ctx, gid, raw), ps_api.Poly.upload(ctx, sc)
+        jobs.append((gid, pts, dsc, dsc.BlindEval(pts)))
+    from playsnark_amd import _lib
+
+    assert _lib.PS_MSM_QUEUE == 3
+    for trio in ((0, 1, 3), (1, 0, 2), (2, 3, 0), (3, 3, 3)):
+        for j in trio:
+            ps_api.msm_launch(ctx, jobs[j][1], jobs[j][2])
+        with pytest.raises(ps_api.PlaysnarkError):  # the queue is full
+            ps_api.msm_launch(ctx, jobs[trio[0]][1], jobs[trio[0]][2])
+        for j in trio:
+            assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3]
+    # steady-state pipelines of depth 2 and 3: launch ahead, finish the oldest
+    order = [0, 1, 3, 0, 0, 1, 2, 3, 1]
+    for depth in (2, 3):
+        launched = finished = 0
+        while finished < len(order):
+            while launched < len(order) and launched - finished < depth:
+                ps_api.msm_launch(ctx, jobs[order[launched]][1], jobs[order[launched]][2])
+                launched += 1
+            j = order[finished]
+            assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3]
+            finished += 1
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.msm_finish(ctx, ps_api.G1)

@@ -64,6 +64,10 @@ def test_quotient_matches_reference_algorithm(ps_api, ctx, co, pr, n):
     assert B.download() == want[1]
     assert Cc.download() == want[2]
     assert h.download() == want[3]
+    # QAP.Quotient alone takes the other route to the same polynomial: values of h on the nodes
+    # n+1..2n-1 (one convolution per aggregate), then a single values -> monomial conversion
+    if n >= 2:
+        assert q.Quotient(ps_api.Poly.upload(ctx, sol)).download() == want[3]
 
 
 def test_quotient_apocalypse_and_sanity(ps_api, ctx, pr):
@@ -102,6 +106,7 @@ def test_quotient_large_n_properties(ps_api, ctx, co, pr):
     lhs = (co.poly_eval(A, t) * co.poly_eval(B, t) - co.poly_eval(Cc, t)) % pr.R
     assert lhs == co.poly_eval(h, t) * zt % pr.R
     assert len(h) == n - 1
+    assert q.Quotient(ps_api.Poly.upload(ctx, sol)).download() == h  # h-only route, same bytes
 
 
 def _points(ps_api, ctx, group, raw):

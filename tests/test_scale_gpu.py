@@ -33,7 +33,13 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     t = {}
     t0 = time.time()
     c, sol = rs.synthetic_circuit(n)
+    # The reference splits the variables at diff = nbVars - nbIO (groth16.go:86, pinochio.go:122) and
+    # treats sol[:diff] as the public part.  Declaring nbIO = nbVars - 3 makes that split fall after
+    # (const, x, out): three public values for the verifier, ~n witness values for the prover's sums --
+    # the shape BASELINE configs #3 / #5 mean (full-size G1 and G2 sums), under the reference's own rule.
+    c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
     m, diff = c.nbVars, c.nbVars - c.nbIO
+    assert diff == 3
     alpha, beta, delta, x, gamma = (rng.fr() for _ in range(5))
     u, v, w, zx = rs.var_poly_evals(c, x)
     t["host_circuit_and_setup_scalars_s"] = time.time() - t0
@@ -54,8 +60,10 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     assert tr.Xi.download(5, 1) == one(co.G1, xi_s[5]) and tr.Xi2.download(n - 1, 1) == one(co.G2, xi_s[n - 1])
     assert tr.XiT.download(n - 2, 1) == one(co.G1, xi_s[n - 2] * pr.fr_div(zx, delta) % R)
     lin = lambda i, div: pr.fr_div((w[i] + beta * u[i] + alpha * v[i]) % R, div)
-    assert tr.NioLP.download() == b"".join(one(co.G1, lin(i, delta)) for i in range(diff, m))
-    assert vk["IoLP"].download(7, 1) == one(co.G1, lin(7, gamma)) and len(vk["IoLP"]) == diff
+    assert len(tr.NioLP) == m - diff and len(vk["IoLP"]) == diff
+    for i in (diff, diff + 1, m // 2, m - 1):
+        assert tr.NioLP.download(i - diff, 1) == one(co.G1, lin(i, delta))
+    assert vk["IoLP"].download() == b"".join(one(co.G1, lin(i, gamma)) for i in range(diff))
     dsol = up(sol)
 
     r, s = rng.fr(), rng.fr()
@@ -63,6 +71,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     t0 = time.time()
     proof = ps_api.Groth16Prove(tr, q, dsol, r, s)
     t["groth16_prove_s"] = time.time() - t0
+    t["groth16_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
 
     # ---- TestGroth16ProofGen at full size ----
     t0 = time.time()
@@ -104,6 +113,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     t0 = time.time()
     pp = ps_api.PHGR13Prove(ek, q, dsol)
     t["phgr13_prove_s"] = time.time() - t0
+    t["phgr13_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
     us, vs_, ws_, zs = rs.var_poly_evals(c, sp)
     ry = rv * rw % R
     dot = lambda ev: sum(e * si for e, si in zip(ev[diff:], sol[diff:])) % R
@@ -120,4 +130,4 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     t["phgr13_verify_s"] = time.time() - t0
     pp.gz = one(co.G1, 12345)
     assert not ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, pp, io)
-    print("SCALE " + json.dumps({"log2n": log2n, "n_vars": m, **{k: round(val, 4) for k, val in t.items()}}))
+    print("SCALE " + json.dumps({"log2n": log2n, "n_vars": m, **{k: (round(val, 4) if isinstance(val, float) else val) for k, val in t.items()}}))
