@@ -132,14 +132,16 @@ def main():
     result = None
     if args.warmup:
         result = msm.run_pipelined(points, scalars, max(args.warmup, args.in_flight), depth=args.in_flight)
-    # one-at-a-time latency, outside the timed region (reported beside the pipelined throughput)
+    # one-at-a-time latency and kernel time, outside the timed region (reported beside the pipelined figures)
+    ctx.set_timing(True)
     barrier()
     t0 = time.perf_counter()
+    single_acc_ms = 0.0
     for _ in range(3):
         msm.run(points, scalars)
+        single_acc_ms += ctx.last_stage_ms()["accumulate"] / 3
     barrier()
     single_ms = (time.perf_counter() - t0) / 3 * 1e3
-    ctx.set_timing(True)
     stage_ms = {k: 0.0 for k in api.Context.STAGES}
 
     def add_stage_times():
@@ -196,13 +198,17 @@ def main():
             },
             "g1_adds_per_s": adds * world * args.steps / elapsed,
             "stage_ms": stage_ms,
+            "stage_note": "per-sum stage times; with in_flight > 1 the stages of neighbouring sums overlap, so they add up to more than ms_per_step",
             "roofline": {
                 "kernel": "k_accumulate<Fp>",
+                "kernel_ms": acc_ms,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "kernel_ms_one_at_a_time": single_acc_ms,
+                "frac_one_at_a_time": (n * BYTES_PER_SCALAR_MUL / (single_acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if single_acc_ms > 0 else 0.0,
                 "traffic": traffic,
                 "note": "integer-ALU bound by construction (SURVEY 8d): see DESIGN.md for the v_mad_u64_u32 roofline",
             },

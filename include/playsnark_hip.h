@@ -119,10 +119,11 @@ typedef struct {
 int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
 int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic, else 4..20 */);
 int ps_msm_set_slice(ps_ctx* ctx, int entries /* sorted entries per accumulation thread; 0 = automatic */);
-/* Per-stage device time of the last MSM, measured with HIP events on the context's own stream
- * (the stream the kernels run on).  Stages: 0 digits (+counter/bucket memsets), 1 scan,
- * 2 scatter, 3 accumulate (the dominant kernel), 4 fix-up, 5 bucket reduction. */
-#define PS_MSM_STAGES 6
+/* Per-stage device time of the sum finished last, measured with HIP events on the streams its kernels
+ * run on.  Stages: 0 digits (+counter memset), 1 scan, 2 scatter, 3 queue (bucket memset, and with
+ * several sums in flight the wait for the previous sum's accumulation), 4 accumulate (the dominant
+ * kernel, bracketed tightly), 5 fix-up, 6 bucket reduction. */
+#define PS_MSM_STAGES 7
 int ps_ctx_set_timing(ps_ctx* ctx, int enable);
 int ps_msm_last_stage_ms(ps_ctx* ctx, float ms[PS_MSM_STAGES]);
 

@@ -75,7 +75,7 @@ class Context:
     def set_slice(self, entries: int):
         _check(lib.ps_msm_set_slice(self._h, entries))
 
-    STAGES = ("digits", "scan", "scatter", "accumulate", "fixup", "reduce")
+    STAGES = ("digits", "scan", "scatter", "queue", "accumulate", "fixup", "reduce")
 
     def set_timing(self, enable: bool):
         _check(lib.ps_ctx_set_timing(self._h, int(enable)))

@@ -611,16 +611,17 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if ((rc = wc->heavy.ensure(4 * (max_heavy + 1)))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
-    int evi = 4;
+    int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
     HIP_TRY(hipMemsetAsync(wc->heavy.p, 0, 4, st));
     HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
+    PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
     hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)wc->buckets.p,
                        (Xyzz<F>*)wc->parts.p);
     if (acc_done) HIP_TRY(hipEventRecord(acc_done, st));
-    PS_STAGE_MARK();  // 4: after accumulate
+    PS_STAGE_MARK();  // 5: after accumulate
     HIP_TRY(hipEventRecord(wc->ev_acc_local, st));
     st = wc->tail;  // ---- the rest runs on the high-priority tail stream ----
     HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
@@ -629,7 +630,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
                        (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (const u32*)wc->heavy.p,
                        (const u32*)wc->heavy.p + 1);
-    PS_STAGE_MARK();  // 5: after fixup
+    PS_STAGE_MARK();  // 6: after fixup
     {
         Xyzz<F>* accs = (Xyzz<F>*)wc->segs.p;
         Xyzz<F>* runs = accs + nseg_total;
@@ -638,10 +639,10 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
                            nseg_total, accs, runs);
         hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
                            (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
-        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3(1), dim3(128), 0, st, (const Xyzz<F>*)l2, red_bits, pl.W,
-                           (Xyzz<F>*)wc->wins.p);
+        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3((unsigned)pl.W), dim3(RED_L3_THREADS * LN), RED_L3_THREADS * sizeof(Xyzz<F>), st,
+                           (const Xyzz<F>*)l2, red_bits, (Xyzz<F>*)wc->wins.p);
     }
-    PS_STAGE_MARK();  // 6: after reduction
+    PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * pl.W,
                            hipMemcpyDeviceToHost, st));
@@ -782,17 +783,18 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
         wc->forced_c = c->forced_c;
         wc->forced_slice = c->forced_slice;
     }
+    // Inputs enqueued on the context stream before the FIRST launch of a burst are visible to the worker
+    // streams: the fork event is recorded while the queue is empty, ahead of that launch's own kernels
+    // (recording it later would order a worker's sort behind the running accumulation).
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (c->q_len == 0) HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     ps_ctx::PendingMsm& e = c->q[(c->q_head + c->q_len) % PS_MSM_QUEUE];
     if (sc->n == 0) {
         e = {pts->group, MsmPlan{}, wc};
     } else {
         MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
         if (c->forced_slice) pl.M = c->forced_slice;
-        if (wc != c) {  // inputs prepared on the context stream are visible to the worker stream
-            if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-            HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
-        }
+        if (wc != c) HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
         // chain the accumulations: this one starts when the previously launched one is done
         hipEvent_t wait = (c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
         int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr);

@@ -478,8 +478,9 @@ __global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ off
 //       run_s = sum B[b]                                   (depth 16, W*NB/8 threads)
 //   L2  window sum = sum_s acc_s + 8 * sum_s s*run_s, and s*run_s is split by the bits of s:
 //       T_k = sum over {s : bit k of s} run_s.  One block per (window, job): job 0 sums the
-//       acc_s, job k+1 sums T_k -- plain tree sums (depth ~ 8 + log2 256)
-//   L3  one thread per window: Horner over the bits, 2^3 shift, + job 0 (depth ~ 2(c-4)+4)
+//       acc_s, job k+1 sums T_k -- plain tree sums (depth ~ 8 + log2 256) -- and then doubles its
+//       result k + 3 times (all jobs in parallel: depth <= c - 2 doublings)
+//   L3  one block per window: tree sum of the c - 3 weighted job results (depth 5)
 constexpr int RED_SEG_LOG = 3;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
 
@@ -534,24 +535,26 @@ __global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTrai
         }
     }
     block_tree_sum<KF>(sm, acc);
-    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
+    if (lt == 0) {  // weight of this job inside the window sum: 1 for job 0, 2^(k + RED_SEG_LOG) for T_k
+        Xyzz<KF> v = ld_xyzz<KF>(&sm[0]);
+        const int shift = job == 0 ? 0 : (int)job - 1 + RED_SEG_LOG;
+        for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
+        st_xyzz<KF>(&out[blockIdx.x], v);
+    }
 }
 
+// one block per window: tree sum of the (already weighted) nbits + 1 job results
+constexpr u32 RED_L3_THREADS = 32;
 template <class KF>
-__global__ void __launch_bounds__(128) k_reduce_l3(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ l2, int nbits, int W,
-                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ win_sums) {
-    int w = (int)logical_tid<KF>();
-    if (w >= W) return;
-    const Xyzz<typename FieldTraits<KF>::Store>* v = l2 + (size_t)w * (nbits + 1);
-    Xyzz<KF> acc = xyzz_identity<KF>();
-    // acc = 2*acc + T_k for the bit sums, then 3 more doublings and + job 0; one inlined doubling and
-    // one inlined addition serve every step (the extra steps add the identity)
-    for (int k = nbits - 1; k >= -RED_SEG_LOG - 1 + 1; k--) {
-        acc = xyzz_dbl_inl<KF>(acc);
-        Xyzz<KF> t = k >= 0 ? ld_xyzz<KF>(&v[1 + k]) : (k == -RED_SEG_LOG ? ld_xyzz<KF>(&v[0]) : xyzz_identity<KF>());
-        xyzz_add_inl<KF>(acc, t);
-    }
-    st_xyzz<KF>(&win_sums[w], acc);
+__global__ void __launch_bounds__(64) k_reduce_l3(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ l2, int nbits,
+                                                  Xyzz<typename FieldTraits<KF>::Store>* __restrict__ win_sums) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
+    const u32 w = blockIdx.x, lt = logical_local<KF>();
+    Xyzz<KF> v = lt <= (u32)nbits ? ld_xyzz<KF>(&l2[(size_t)w * (nbits + 1) + lt]) : xyzz_identity<KF>();
+    block_tree_sum<KF>(sm, v);
+    if (lt == 0) st_xyzz<KF>(&win_sums[w], ld_xyzz<KF>(&sm[0]));
 }
 
 // ---------------------------------------------------------------------------------------

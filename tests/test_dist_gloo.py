@@ -43,3 +43,36 @@ def test_sharded_msm_exchange_two_ranks(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_pipelined_runner_keeps_depth_and_order(monkeypatch):
+    """Host logic of ShardedMsm.run_pipelined (the loop bench.py times): never more than `depth` sums
+    pending, every launched sum is finished, results come back in launch order.  The GPU entry points
+    are replaced by a recording FIFO; the queue itself is tested on the GPU (test_msm_gpu.py)."""
+    from playsnark_amd import api
+    from playsnark_amd.dist import ShardedMsm
+
+    for depth in (1, 2, 3):
+        for steps in (1, 2, 5):
+            pending, log, counter = [], [], [0]
+
+            def launch(ctx, points, scalars):
+                assert len(pending) < depth
+                counter[0] += 1
+                pending.append(counter[0])
+                log.append(("L", counter[0], len(pending)))
+
+            def finish(ctx, group):
+                k = pending.pop(0)
+                log.append(("F", k, len(pending)))
+                return k.to_bytes(4, "big")
+
+            monkeypatch.setattr(api, "msm_launch", launch)
+            monkeypatch.setattr(api, "msm_finish", finish)
+            seen = []
+            last = ShardedMsm(None, api.G1).run_pipelined(None, None, steps, on_step=lambda: seen.append(len(pending)), depth=depth)
+            assert not pending and counter[0] == steps and len(seen) == steps
+            assert [k for op, k, _ in log if op == "F"] == list(range(1, steps + 1))
+            assert last == steps.to_bytes(4, "big")
+            if steps >= depth:
+                assert max(p for _, _, p in log) == depth
