@@ -184,4 +184,25 @@ inline ps_groth16_crs NewGroth16TrustedSetup(Context& c, const QAP& q, const ps_
     return out;
 }
 
+// func NewPHGR13TrustedSetup(qap QAP) PHGR13Setup (pinochio.go:93), toxic waste drawn by the caller;
+// release the arrays with ps_phgr13_crs_free
+inline ps_phgr13_crs NewPHGR13TrustedSetup(Context& c, const QAP& q, const ps_phgr13_toxic& tw) {
+    ps_phgr13_crs out;
+    check(ps_phgr13_setup(c.get(), q.get(), &tw, &out));
+    return out;
+}
+// computeSolCommit for several evaluation-key arrays at once (pinochio.go:222-241): one digit sort
+inline std::vector<Bytes> SolCommits(Context& c, const std::vector<const Points*>& arrays, const Poly& sol) {
+    std::vector<const ps_points*> pts;
+    std::vector<Bytes> out;
+    std::vector<uint8_t*> dst;
+    for (auto* a : arrays) {
+        pts.push_back(a->get());
+        out.emplace_back(a->group() == PS_G1 ? 96 : 192);
+    }
+    for (auto& o : out) dst.push_back(o.data());
+    check(ps_msm_multi(c.get(), pts.data(), pts.size(), sol.get(), dst.data()));
+    return out;
+}
+
 }  // namespace playsnark
