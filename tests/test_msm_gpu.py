@@ -277,3 +277,51 @@ def test_two_sums_in_flight_fifo(ps_api, ctx, co, pr):
             finished += 1
     with pytest.raises(ps_api.PlaysnarkError):
         ps_api.msm_finish(ctx, ps_api.G1)
+
+
+def test_msm_multi_limits(ps_api, ctx, co, pr):
+    """PS_MSM_MULTI_MAX arrays in one call; one more is refused; zero arrays is a no-op."""
+    rng = _rng(pr, 9100)
+    n = 40
+    sc = [rng.fr() for _ in range(n)]
+    dsc = ps_api.Poly.upload(ctx, sc)
+    raws = [co.G1.gen_points(rng.fr(), rng.fr(), n) for _ in range(16)]
+    pts = [ps_api.Points.upload(ctx, ps_api.G1, raw) for raw in raws]
+    got = ps_api.msm_multi(ctx, pts, dsc)
+    assert got == [co.G1.to_b(co.G1.blind_eval(sc, raw)) for raw in raws]
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.msm_multi(ctx, pts + [pts[0]], dsc)
+    assert ps_api.msm_multi(ctx, [], dsc) == []
+
+
+def test_pending_queue_random_schedule(ps_api, ctx, co, pr):
+    """A seeded random schedule of launches and finishes over sums of different sizes and groups, with
+    one-at-a-time calls and multi-array calls in between whenever the queue is empty: every result
+    equals the one-at-a-time result."""
+    from playsnark_amd import _lib
+
+    rng = _rng(pr, 9200)
+    jobs = []
+    for gid, og, n in ((ps_api.G1, co.G1, 3), (ps_api.G1, co.G1, 900), (ps_api.G2, co.G2, 130), (ps_api.G1, co.G1, 4100),
+                       (ps_api.G2, co.G2, 1), (ps_api.G1, co.G1, 0)):
+        sc = [rng.fr() for _ in range(n)]
+        raw = og.gen_points(rng.fr(), rng.fr(), n)
+        pts, dsc = ps_api.Points.upload(ctx, gid, raw), ps_api.Poly.upload(ctx, sc)
+        jobs.append((gid, pts, dsc, dsc.BlindEval(pts)))
+    pending = []
+    for step in range(60):
+        r = rng.next() % 100
+        if pending and (len(pending) == _lib.PS_MSM_QUEUE or r < 45):
+            j = pending.pop(0)
+            assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3], (step, j)
+        elif not pending and r >= 90:
+            j = rng.next() % len(jobs)
+            assert jobs[j][2].BlindEval(jobs[j][1]) == jobs[j][3]
+            assert ps_api.msm_multi(ctx, [jobs[j][1], jobs[j][1]], jobs[j][2]) == [jobs[j][3]] * 2
+        else:
+            j = rng.next() % len(jobs)
+            ps_api.msm_launch(ctx, jobs[j][1], jobs[j][2])
+            pending.append(j)
+    while pending:
+        j = pending.pop(0)
+        assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3]

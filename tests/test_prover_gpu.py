@@ -263,3 +263,23 @@ def test_phgr13_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     assert not ps_api.PHGR13Verify(ctx, vk.fixed_points(), *args, proof, ps_api.Poly.upload(ctx, bad_io))
     with pytest.raises(ps_api.PlaysnarkError):  # s on the interpolation domain
         ps_api.NewPHGR13TrustedSetup(q, 2, *tox[1:])
+
+
+def test_phgr13_arrays_of_unequal_length(ps_api, ctx, co, pr):
+    """computeSolCommit (pinochio.go:222-229) ranges over len(evalCommit): an evaluation key whose
+    arrays differ in length (not what the setup produces) takes the one-sum-at-a-time path and still
+    matches the oracle element by element."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 777)
+    c, sol = rs.synthetic_circuit(40)
+    c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)  # 3 public, the rest in the sums
+    setup = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    ek = setup.EK
+    ek.vs = ek.vs[:-96]      # one G1 point shorter
+    ek.ws = ek.ws[:-2 * 192]  # two G2 points shorter
+    want = rs.phgr13_prove(ek, c, sol, fast=True)
+    q = _upload_circuit(ps_api, ctx, c)
+    proof = ps_api.PHGR13Prove(_phgr13_ek(ps_api, ctx, ek), q, ps_api.Poly.upload(ctx, sol))
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(proof, f) == getattr(want, f), f
