@@ -51,7 +51,7 @@ constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
 // forward transform and 0..k-1 for the inverse.  Column q = (hi, lo) with lo = q mod D; element
 // (t, q) lives at hi*D*2^k + t*D + lo.
 template <bool INV>
-__global__ void __launch_bounds__(1024) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+__global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
                                                   const Fr* __restrict__ tw, int log_tab) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
@@ -69,34 +69,85 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(Fr* __restrict__ data, int p,
         tile[t * COLS + col] = data[addr];
     }
     __syncthreads();
-    const u32 nbf = (rows >> 1) << logCols;
-    for (int st = 0; st < k; st++) {
-        const int m = INV ? st : (k - 1 - st);
-        const u32 mmask = (1u << m) - 1;
-        const int logh = logD + m;          // half-distance 2^logh
-        const int M = p - 1 - logh;         // this stage has 2^M blocks per transform
-        for (u32 bf = threadIdx.x; bf < nbf; bf += blockDim.x) {
-            u32 col = bf & (COLS - 1), r = bf >> logCols;
-            u32 t0 = ((r >> m) << (m + 1)) | (r & mmask), t1 = t0 | (1u << m);
-            u64 q = q0 + col;
-            u64 i0 = ((q >> logD) << (logD + k)) + ((u64)t0 << logD) + (q & Dm1);
-            u32 blk = (u32)((i0 & smask) >> (logh + 1));
-            Fr a = tile[t0 * COLS + col], b = tile[t1 * COLS + col];
-            if (M > 0) {
-                u32 widx = (__brev(blk) >> (32 - M)) << (log_tab - 1 - M);
-                Fr w = tw[widx];
+    // global index of element (row t, column col) of this tile, and the twiddle of the butterfly block
+    // that holds global index i at a stage with half-distance 2^logh (returns false when w = 1)
+    auto gidx = [&](u32 t, u32 col) -> u64 {
+        const u64 q = q0 + col;
+        return ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
+    };
+    auto twiddle = [&](u64 i, int logh, Fr& w) -> bool {
+        const int M = p - 1 - logh;  // this stage has 2^M blocks per transform
+        if (M <= 0) return false;    // the single block of the outermost stage: w = 1
+        const u32 blk = (u32)((i & smask) >> (logh + 1));
+        w = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
+        return true;
+    };
+    // Two butterfly stages per LDS round trip where possible: a thread takes the four rows that differ
+    // in row bits m and m+1, so loads, stores, index arithmetic and barriers are halved.  Forward
+    // (Cooley-Tukey) walks m = k-1 .. 0, inverse (Gentleman-Sande) m = 0 .. k-1.
+    const u32 nbf = (rows >> 1) << logCols, nq = (rows >> 2) << logCols;
+    int done_st = 0;
+    while (done_st < k) {
+        const int left = k - done_st;
+        // an odd stage count runs its single stage first (forward) / last (inverse)
+        const bool single = (left == 1) || (!INV && (left & 1));
+        if (single) {
+            const int m = INV ? done_st : (k - 1 - done_st);
+            const u32 mmask = (1u << m) - 1;
+            const int logh = logD + m;
+            for (u32 bf = threadIdx.x; bf < nbf; bf += blockDim.x) {
+                u32 col = bf & (COLS - 1), r = bf >> logCols;
+                u32 t0 = ((r >> m) << (m + 1)) | (r & mmask), t1 = t0 | (1u << m);
+                Fr a = tile[t0 * COLS + col], b = tile[t1 * COLS + col], w;
+                const bool has_w = twiddle(gidx(t0, col), logh, w);
                 if (!INV) {
-                    Fr wb = fr_mul(b, w);
+                    Fr wb = has_w ? fr_mul(b, w) : b;
                     tile[t0 * COLS + col] = fr_norm(fr_add(a, wb));
                     tile[t1 * COLS + col] = fr_norm(fr_sub(a, wb));
                 } else {
                     tile[t0 * COLS + col] = fr_norm(fr_add(a, b));
-                    tile[t1 * COLS + col] = fr_mul(fr_norm(fr_sub(a, b)), w);
+                    Fr d = fr_norm(fr_sub(a, b));
+                    tile[t1 * COLS + col] = has_w ? fr_mul(d, w) : d;
                 }
-            } else {  // the single block of the outermost stage: w = 1
-                tile[t0 * COLS + col] = fr_norm(fr_add(a, b));
-                tile[t1 * COLS + col] = fr_norm(fr_sub(a, b));
             }
+            done_st += 1;
+        } else {
+            const int m_lo = INV ? done_st : (k - 2 - done_st), m_hi = m_lo + 1;
+            const u32 lowmask = (1u << m_lo) - 1;
+            for (u32 qd = threadIdx.x; qd < nq; qd += blockDim.x) {
+                u32 col = qd & (COLS - 1), r = qd >> logCols;
+                u32 t00 = ((r >> m_lo) << (m_lo + 2)) | (r & lowmask);
+                u32 t01 = t00 | (1u << m_lo), t10 = t00 | (1u << m_hi), t11 = t10 | (1u << m_lo);
+                Fr a = tile[t00 * COLS + col], b = tile[t01 * COLS + col], c = tile[t10 * COLS + col], d = tile[t11 * COLS + col];
+                const u64 i00 = gidx(t00, col), i10 = gidx(t10, col);
+                Fr w;
+                if (!INV) {
+                    // stage m_hi: (a, c), (b, d) share one block; stage m_lo: (a', b') and (c', d')
+                    if (twiddle(i00, logD + m_hi, w)) { c = fr_mul(c, w); d = fr_mul(d, w); }
+                    Fr a1 = fr_add(a, c), c1 = fr_sub(a, c), b1 = fr_add(b, d), d1 = fr_sub(b, d);  // class 2, fresh sums
+                    twiddle(i00, logD + m_lo, w);  // m_lo < k-1: never the outermost stage
+                    Fr wb = fr_mul(b1, w);
+                    tile[t00 * COLS + col] = fr_norm(fr_add(a1, wb));
+                    tile[t01 * COLS + col] = fr_norm(fr_sub(a1, wb));
+                    twiddle(i10, logD + m_lo, w);
+                    Fr wd = fr_mul(d1, w);
+                    tile[t10 * COLS + col] = fr_norm(fr_add(c1, wd));
+                    tile[t11 * COLS + col] = fr_norm(fr_sub(c1, wd));
+                } else {
+                    // stage m_lo: (a, b) and (c, d) in neighbouring blocks; stage m_hi: (a', c'), (b', d')
+                    twiddle(i00, logD + m_lo, w);  // m_lo < the outermost stage: always a real twiddle
+                    Fr a1 = fr_add(a, b), b1 = fr_mul(fr_norm(fr_sub(a, b)), w);
+                    twiddle(i10, logD + m_lo, w);
+                    Fr c1 = fr_add(c, d), d1 = fr_mul(fr_norm(fr_sub(c, d)), w);
+                    const bool has_w = twiddle(i00, logD + m_hi, w);
+                    tile[t00 * COLS + col] = fr_norm(fr_add(a1, c1));
+                    tile[t01 * COLS + col] = fr_norm(fr_add(b1, d1));
+                    Fr e = fr_norm(fr_sub(a1, c1)), f = fr_norm(fr_sub(b1, d1));
+                    tile[t10 * COLS + col] = has_w ? fr_mul(e, w) : e;
+                    tile[t11 * COLS + col] = has_w ? fr_mul(f, w) : f;
+                }
+            }
+            done_st += 2;
         }
         __syncthreads();
     }
@@ -164,8 +215,9 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         u64 cols_total = total >> k;
         unsigned grid = (unsigned)(cols_total >> logCols);
         size_t smem = ((size_t)sizeof(Fr) << k) << logCols;
-        // one butterfly per thread and stage: 4 waves per SIMD hide the LDS and multiplier latency
-        unsigned threads = (unsigned)std::min<u64>(1024, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 1));
+        // one four-row group per thread and double stage; two 512-thread workgroups share a CU (2 x 80 KB
+        // of LDS), so 4 waves per SIMD hide the LDS and multiplier latency
+        unsigned threads = (unsigned)std::min<u64>(512, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 2));
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
                            INV ? tb.inv : tb.fwd, tb.log_tab);
         done += k;
