@@ -50,9 +50,29 @@ constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
 // One pass over transforms of 2^p points: k stages with half-distances D*2^m, m = k-1..0 for the
 // forward transform and 0..k-1 for the inverse.  Column q = (hi, lo) with lo = q mod D; element
 // (t, q) lives at hi*D*2^k + t*D + lo.
+// Element-wise work folded into the first pass's load and the last pass's store of a transform, so the
+// Newton -> monomial levels (quotient.cuh) need no separate prepare / multiply / combine kernels:
+//   load  NTT_LD_UPPER_HALF   x[node*s + i] = i < s/2 ? src[node*s + s/2 + i] : 0      (s = 2^logs)
+//   store NTT_ST_MUL          out = value * aux[index]
+//   store NTT_ST_COMBINE      dst[node*s + i] = (i < s/2 ? dst[node*s + i] : 0) + value
+//   load  NTT_LD_SCALE_PAD    x[i] = i < cnt ? src[i] * aux[i] : 0
+//   store NTT_ST_TAKE         dst[i] = value for i < cnt (nothing else is written)
+enum { NTT_LD_PLAIN = 0, NTT_LD_UPPER_HALF = 1, NTT_LD_SCALE_PAD = 2 };
+enum { NTT_ST_PLAIN = 0, NTT_ST_MUL = 1, NTT_ST_COMBINE = 2, NTT_ST_TAKE = 3 };
+struct NttFuse {
+    int ld = NTT_LD_PLAIN;
+    const Fr* ld_src = nullptr;   // UPPER_HALF / SCALE_PAD: the array read instead of `data`
+    const Fr* ld_aux = nullptr;   // SCALE_PAD: the per-element factors
+    int st = NTT_ST_PLAIN;
+    const Fr* st_aux = nullptr;   // MUL: the per-element factors
+    Fr* st_dst = nullptr;         // COMBINE / TAKE: the array written instead of `data`
+    int logs = 0;                 // UPPER_HALF / COMBINE: node size
+    u64 cnt = 0;                  // SCALE_PAD / TAKE: element count
+};
+
 template <bool INV>
 __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
-                                                  const Fr* __restrict__ tw, int log_tab) {
+                                                  const Fr* __restrict__ tw, int log_tab, NttFuse fz) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
     const u32 COLS = 1u << logCols, rows = 1u << k;
@@ -66,7 +86,16 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
         else { u32 lo = e & (u32)Dm1; t = (e >> logD) & (rows - 1); u32 hl = e >> (logD + k); col = (hl << logD) | lo; }
         u64 q = q0 + col;
         u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
-        tile[t * COLS + col] = data[addr];
+        Fr v;
+        if (fz.ld == NTT_LD_PLAIN) {
+            v = data[addr];
+        } else if (fz.ld == NTT_LD_UPPER_HALF) {
+            const u64 half = 1ull << (fz.logs - 1);
+            v = (addr & (2 * half - 1)) < half ? fz.ld_src[addr + half] : fr_zero();
+        } else {
+            v = addr < fz.cnt ? fr_mul(fz.ld_src[addr], fz.ld_aux[addr]) : fr_zero();
+        }
+        tile[t * COLS + col] = v;
     }
     __syncthreads();
     // global index of element (row t, column col) of this tile, and the twiddle of the butterfly block
@@ -164,7 +193,16 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
         u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
         Fr v = tile[t * COLS + col];
         if (INV) v = fr_mul(v, sc);  // 2^-k of this pass; also pulls the doubled values back under ~r
-        data[addr] = v;
+        if (fz.st == NTT_ST_PLAIN) {
+            data[addr] = v;
+        } else if (fz.st == NTT_ST_MUL) {
+            data[addr] = fr_mul(v, fz.st_aux[addr]);
+        } else if (fz.st == NTT_ST_COMBINE) {
+            const u64 half = 1ull << (fz.logs - 1);
+            fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
+        } else if (addr < fz.cnt) {
+            fz.st_dst[addr] = v;
+        }
     }
 }
 
@@ -199,8 +237,8 @@ static inline hipError_t ntt_tables_ensure(NttTables& t, int log_size, hipStream
 
 // `total` = batch * 2^p elements, contiguous.  Forward: natural -> bit-reversed (per block).
 template <bool INV>
-static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p) {
-    if (p == 0) return hipSuccess;
+static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p, const NttFuse& fuse = NttFuse()) {
+    if (p == 0) return (fuse.ld || fuse.st) ? hipErrorInvalidValue : hipSuccess;
     if (p > tb.log_tab) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
     int npass = (p + NTT_MAX_K - 1) / NTT_MAX_K;
@@ -218,8 +256,13 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         // one four-row group per thread and double stage; two 512-thread workgroups share a CU (2 x 80 KB
         // of LDS), so 4 waves per SIMD hide the LDS and multiplier latency
         unsigned threads = (unsigned)std::min<u64>(512, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 2));
+        NttFuse fz;  // the load belongs to the first pass, the store to the last
+        if (ps_i == 0) { fz.ld = fuse.ld; fz.ld_src = fuse.ld_src; fz.ld_aux = fuse.ld_aux; }
+        if (ps_i == npass - 1) { fz.st = fuse.st; fz.st_aux = fuse.st_aux; fz.st_dst = fuse.st_dst; }
+        fz.logs = fuse.logs;
+        fz.cnt = fuse.cnt;
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
-                           INV ? tb.inv : tb.fwd, tb.log_tab);
+                           INV ? tb.inv : tb.fwd, tb.log_tab, fz);
         done += k;
     }
     return hipGetLastError();

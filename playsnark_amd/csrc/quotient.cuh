@@ -340,11 +340,15 @@ static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t s
                                             u64 off, Fr* data, Fr* scratch) {
     hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64), off);
     for (int logs = 7; logs <= lognp; logs++) {
-        hipLaunchKernelGGL(k_level_prepare, dim3(nblk(np)), dim3(256), 0, st, scratch, data, np, logs);
-        QT_TRY(ntt_run<false>(tabs, st, scratch, np, logs));
-        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(np)), dim3(256), 0, st, scratch, scratch, zhat[logs], np);
-        QT_TRY(ntt_run<true>(tabs, st, scratch, np, logs));
-        hipLaunchKernelGGL(k_level_combine, dim3(nblk(np)), dim3(256), 0, st, data, scratch, np, logs);
+        // scratch = NTT(upper halves of the nodes, zero-padded) * zhat ; data = lower halves + INTT(scratch):
+        // prepare, multiply and combine ride on the first load / last store of the two transforms
+        NttFuse f;
+        f.ld = NTT_LD_UPPER_HALF; f.ld_src = data; f.logs = logs;
+        f.st = NTT_ST_MUL; f.st_aux = zhat[logs];
+        QT_TRY(ntt_run<false>(tabs, st, scratch, np, logs, f));
+        NttFuse g;
+        g.st = NTT_ST_COMBINE; g.st_dst = data; g.logs = logs;
+        QT_TRY(ntt_run<true>(tabs, st, scratch, np, logs, g));
     }
     return hipGetLastError();
 }
@@ -353,11 +357,15 @@ static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t s
 // The divided differences of equally spaced nodes do not depend on `off`: d_k = sum_j (y_j / j!) (-1)^(k-j) / (k-j)!.
 static inline hipError_t interpolate_on_nodes(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y, u64 cnt,
                                               u64 np, int lognp, const Fr* vhat, const std::vector<Fr*>& zhat, u64 off) {
-    hipLaunchKernelGGL(k_scale_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, y, qt.invfact, cnt, 2 * np);
-    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, lognp + 1));
-    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(2 * np)), dim3(256), 0, st, qt.t1, qt.t1, vhat, 2 * np);
-    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, lognp + 1));
-    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(np)), dim3(256), 0, st, qt.data, qt.t1, cnt, np);
+    // t1 = INTT(NTT(y_j / j!, zero-padded) * vhat); data = its first cnt entries, zero up to np
+    NttFuse f;
+    f.ld = NTT_LD_SCALE_PAD; f.ld_src = y; f.ld_aux = qt.invfact; f.cnt = cnt;
+    f.st = NTT_ST_MUL; f.st_aux = vhat;
+    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, lognp + 1, f));
+    QT_TRY(hipMemsetAsync(qt.data, 0, sizeof(Fr) * np, st));
+    NttFuse g;
+    g.st = NTT_ST_TAKE; g.st_dst = qt.data; g.cnt = cnt;
+    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, lognp + 1, g));
     return newton_to_monomial(tabs, st, np, lognp, zhat, off, qt.data, qt.scratch);
 }
 // values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
