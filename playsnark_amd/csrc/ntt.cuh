@@ -56,9 +56,12 @@ constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
 //   store NTT_ST_MUL          out = value * aux[index]
 //   store NTT_ST_COMBINE      dst[node*s + i] = (i < s/2 ? dst[node*s + i] : 0) + value
 //   load  NTT_LD_SCALE_PAD    x[i] = i < cnt ? src[i] * aux[i] : 0
+//   load  NTT_LD_PAD          x[i] = i < cnt ? src[i] : 0
+//   load  NTT_LD_REV_PAD      x[i] = i < cnt ? src[top - i] : 0
 //   store NTT_ST_TAKE         dst[i] = value for i < cnt (nothing else is written)
-enum { NTT_LD_PLAIN = 0, NTT_LD_UPPER_HALF = 1, NTT_LD_SCALE_PAD = 2 };
-enum { NTT_ST_PLAIN = 0, NTT_ST_MUL = 1, NTT_ST_COMBINE = 2, NTT_ST_TAKE = 3 };
+//   store NTT_ST_REV_TAKE     dst[top - i] = value for i < cnt
+enum { NTT_LD_PLAIN = 0, NTT_LD_UPPER_HALF = 1, NTT_LD_SCALE_PAD = 2, NTT_LD_PAD = 3, NTT_LD_REV_PAD = 4 };
+enum { NTT_ST_PLAIN = 0, NTT_ST_MUL = 1, NTT_ST_COMBINE = 2, NTT_ST_TAKE = 3, NTT_ST_REV_TAKE = 4 };
 struct NttFuse {
     int ld = NTT_LD_PLAIN;
     const Fr* ld_src = nullptr;   // UPPER_HALF / SCALE_PAD: the array read instead of `data`
@@ -67,7 +70,8 @@ struct NttFuse {
     const Fr* st_aux = nullptr;   // MUL: the per-element factors
     Fr* st_dst = nullptr;         // COMBINE / TAKE: the array written instead of `data`
     int logs = 0;                 // UPPER_HALF / COMBINE: node size
-    u64 cnt = 0;                  // SCALE_PAD / TAKE: element count
+    u64 cnt = 0;                  // *_PAD / *TAKE: element count
+    u64 top = 0;                  // REV_PAD / REV_TAKE: index that maps to 0
 };
 
 template <bool INV>
@@ -92,8 +96,12 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
         } else if (fz.ld == NTT_LD_UPPER_HALF) {
             const u64 half = 1ull << (fz.logs - 1);
             v = (addr & (2 * half - 1)) < half ? fz.ld_src[addr + half] : fr_zero();
-        } else {
+        } else if (fz.ld == NTT_LD_SCALE_PAD) {
             v = addr < fz.cnt ? fr_mul(fz.ld_src[addr], fz.ld_aux[addr]) : fr_zero();
+        } else if (fz.ld == NTT_LD_PAD) {
+            v = addr < fz.cnt ? fz.ld_src[addr] : fr_zero();
+        } else {
+            v = addr < fz.cnt ? fz.ld_src[fz.top - addr] : fr_zero();
         }
         tile[t * COLS + col] = v;
     }
@@ -201,7 +209,7 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
             const u64 half = 1ull << (fz.logs - 1);
             fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
         } else if (addr < fz.cnt) {
-            fz.st_dst[addr] = v;
+            fz.st_dst[fz.st == NTT_ST_TAKE ? addr : fz.top - addr] = v;
         }
     }
 }
@@ -261,6 +269,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         if (ps_i == npass - 1) { fz.st = fuse.st; fz.st_aux = fuse.st_aux; fz.st_dst = fuse.st_dst; }
         fz.logs = fuse.logs;
         fz.cnt = fuse.cnt;
+        fz.top = fuse.top;
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
                            INV ? tb.inv : tb.fwd, tb.log_tab, fz);
         done += k;

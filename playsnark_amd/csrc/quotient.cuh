@@ -386,8 +386,9 @@ static inline hipError_t quotient_h_only(const NttTables& tabs, hipStream_t st, 
     Fr* S[3] = {qt.t1, qt.pa, qt.pb};
     for (int k = 0; k < 3; k++) {
         hipLaunchKernelGGL(k_lagrange_weights, dim3(nblk(L)), dim3(256), 0, st, S[k], ys[k], qt.invfact, n, L);
-        QT_TRY(ntt_run<false>(tabs, st, S[k], L, qt.lognp + 1));
-        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(L)), dim3(256), 0, st, S[k], S[k], qt.rhat, L);
+        NttFuse f;
+        f.st = NTT_ST_MUL; f.st_aux = qt.rhat;
+        QT_TRY(ntt_run<false>(tabs, st, S[k], L, qt.lognp + 1, f));
         QT_TRY(ntt_run<true>(tabs, st, S[k], L, qt.lognp + 1));
     }
     Fr* hv = qt.scratch;
@@ -402,19 +403,29 @@ static inline hipError_t quotient_from_AB(const NttTables& tabs, hipStream_t st,
     const u64 n = qt.n;
     if (n < 2) return hipSuccess;
     const u64 Sp = 1ull << qt.pp, Sh = 1ull << qt.ph;
-    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(Sp)), dim3(256), 0, st, qt.pa, A, n, Sp);
-    hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(Sp)), dim3(256), 0, st, qt.pb, B, n, Sp);
-    QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sp, qt.pp));
-    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sp, qt.pp));
-    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(Sp)), dim3(256), 0, st, qt.pa, qt.pa, qt.pb, Sp);
-    QT_TRY(ntt_run<true>(tabs, st, qt.pa, Sp, qt.pp));
-    // q_i = P_{2n-2-i}, i < n-1
-    hipLaunchKernelGGL(k_rev_take, dim3(nblk(Sh)), dim3(256), 0, st, qt.pb, qt.pa, 2 * n - 2, n - 1, Sh);
-    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sh, qt.ph));
-    hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(nblk(Sh)), dim3(256), 0, st, qt.pb, qt.pb, qt.ghat, Sh);
-    QT_TRY(ntt_run<true>(tabs, st, qt.pb, Sh, qt.ph));
-    // h_{n-2-i} = (q*g)_i
-    hipLaunchKernelGGL(k_rev_take, dim3(nblk(n - 1)), dim3(256), 0, st, h_out, qt.pb, n - 2, n - 1, n - 1);
+    // pb = INTT(NTT(A) * NTT(B)): the zero-padding rides on the loads, the product on B's last store
+    NttFuse fa;
+    fa.ld = NTT_LD_PAD; fa.ld_src = A; fa.cnt = n;
+    QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sp, qt.pp, fa));
+    NttFuse fb;
+    fb.ld = NTT_LD_PAD; fb.ld_src = B; fb.cnt = n;
+    fb.st = NTT_ST_MUL; fb.st_aux = qt.pa;
+    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sp, qt.pp, fb));
+    QT_TRY(ntt_run<true>(tabs, st, qt.pb, Sp, qt.pp));
+    // q_i = P_{2n-2-i}, i < n-1, times the inverse series; h_{n-2-i} = (q*g)_i
+    if (qt.ph == 0) {  // n = 2: one coefficient, transforms of size 1
+        hipLaunchKernelGGL(k_rev_take, dim3(1), dim3(256), 0, st, qt.pa, (const Fr*)qt.pb, 2 * n - 2, n - 1, Sh);
+        hipLaunchKernelGGL(k_fr_pointwise_mul, dim3(1), dim3(256), 0, st, qt.pa, (const Fr*)qt.pa, (const Fr*)qt.ghat, Sh);
+        hipLaunchKernelGGL(k_rev_take, dim3(1), dim3(256), 0, st, h_out, (const Fr*)qt.pa, n - 2, n - 1, n - 1);
+        return hipGetLastError();
+    }
+    NttFuse fq;
+    fq.ld = NTT_LD_REV_PAD; fq.ld_src = qt.pb; fq.top = 2 * n - 2; fq.cnt = n - 1;
+    fq.st = NTT_ST_MUL; fq.st_aux = qt.ghat;
+    QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sh, qt.ph, fq));
+    NttFuse fh;
+    fh.st = NTT_ST_REV_TAKE; fh.st_dst = h_out; fh.top = n - 2; fh.cnt = n - 1;
+    QT_TRY(ntt_run<true>(tabs, st, qt.pa, Sh, qt.ph, fh));
     return hipGetLastError();
 }
 
