@@ -39,18 +39,15 @@ static inline void quotient_cache_free(QuotientCache* q) {
 // ---------------------------------------------------------------------------------------
 __device__ inline Fr fr_shfl_up1(const Fr& v) {  // lane l gets lane l-1's value, lane 0 gets 0
     Fr r;
-    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < FR_L; j++) {
-        i32 t = __shfl_up(v.l[j], 1, 64);
-        r.l[j] = lane == 0 ? 0 : t;
-    }
+    for (int j = 0; j < FR_L; j++)  // DPP wave_shr:1 (0x138), bound_ctrl: lane 0 reads 0 -- one v_mov_dpp per limb
+        r.l[j] = __builtin_amdgcn_update_dpp(0, v.l[j], 0x138, 0xF, 0xF, true);
     return r;
 }
-__device__ inline Fr fr_shfl(const Fr& v, int src) {
+__device__ inline Fr fr_shfl(const Fr& v, int src) {  // broadcast of lane `src` (uniform): v_readlane
     Fr r;
 #pragma unroll
-    for (int j = 0; j < FR_L; j++) r.l[j] = __shfl(v.l[j], src, 64);
+    for (int j = 0; j < FR_L; j++) r.l[j] = __builtin_amdgcn_readlane(v.l[j], src);
     return r;
 }
 
