@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
     ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
                     help="sums kept in flight per GPU (k: step i+k-1 is enqueued before step i is folded)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus > 1 (gloo + PS_BENCH_DEVICE=0 rehearses the multi-rank "
+                         "path on a one-GPU box; the driver's runs use nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="CPU baseline MSM size (default: the full workload)")
     args = ap.parse_args()
@@ -96,13 +99,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if "PS_BENCH_DEVICE" in os.environ:  # rehearsal on a one-GPU box: every rank on the same device
+        local_rank = int(os.environ["PS_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from playsnark_amd import api
     from playsnark_amd.dist import ShardedMsm
@@ -154,7 +162,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = ctx.last_msm_info()
