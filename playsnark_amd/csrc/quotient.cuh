@@ -15,7 +15,11 @@
 //      log2(n/64) levels  N = N_left + Z_left * N_right  with the subproduct tree
 //      Z = prod (x - i) kept in NTT form in HBM (n log n Fr elements; 288 GB makes that free)
 //   5. h = floor(A*B / z) (C = A*B mod z never needs interpolating): reversed power-series
-//      division with rev(z)^-1 mod x^(n-1) precomputed per n
+//      division with rev(z)^-1 mod x^(n-1) precomputed per n              [Groth16Prove: A, B needed]
+//   6. h alone: values of A, B, C on the nodes n+1..2n-1 by one convolution each, h there point-wise,
+//      then steps 3-4 once on a second tree over the shifted nodes     [PHGR13Prove, QAP.Quotient]
+// The element-wise work around the transforms (padding, products with stored transforms, adding halves
+// back) is folded into the first load / last store of the NTT passes (ntt.cuh, NttFuse).
 // Everything per-n (factorials, tree, z, inverse series) is built once in ps_qap_create.
 #pragma once
 #include <vector>
@@ -92,25 +96,8 @@ __global__ void __launch_bounds__(256) k_subproduct_base(Fr* __restrict__ out, u
 }
 
 // ---------------------------------------------------------------------------------------
-// level kernels
+// subproduct-tree kernels (the level steps themselves ride on the NTT passes, see NttFuse)
 // ---------------------------------------------------------------------------------------
-// scratch[node*s + i] = i < s/2 ? data[node*s + s/2 + i] : 0
-__global__ void __launch_bounds__(256) k_level_prepare(Fr* __restrict__ scratch, const Fr* __restrict__ data, u64 total, int logs) {
-    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    u64 half = 1ull << (logs - 1);
-    u64 i = idx & ((1ull << logs) - 1);
-    scratch[idx] = i < half ? data[idx + half] : fr_zero();
-}
-// data[node*s + i] = (i < s/2 ? data[node*s + i] : 0) + scratch[node*s + i]
-__global__ void __launch_bounds__(256) k_level_combine(Fr* __restrict__ data, const Fr* __restrict__ scratch, u64 total, int logs) {
-    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    u64 half = 1ull << (logs - 1);
-    u64 i = idx & ((1ull << logs) - 1);
-    Fr s = scratch[idx];
-    data[idx] = i < half ? fr_norm(fr_add(data[idx], s)) : s;
-}
 // full[node*2t + i] = i < t ? F[node*t + i] : (i == t ? 1 : 0)
 __global__ void __launch_bounds__(256) k_tree_expand(Fr* __restrict__ full, const Fr* __restrict__ F, u64 total2, int logt) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,13 +169,6 @@ __global__ void __launch_bounds__(256) k_check_gates(const Fr* __restrict__ yA, 
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     if (!fr_is_zero(fr_sub(fr_mul(yA[r], yB[r]), yC[r]))) atomicOr(flag, 1u);
-}
-// out[j] = j < n ? y[j] * invfact[j] : 0   for j < total
-__global__ void __launch_bounds__(256) k_scale_pad(Fr* __restrict__ out, const Fr* __restrict__ y, const Fr* __restrict__ invfact,
-                                                   u64 n, u64 total) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
-    out[j] = j < n ? fr_mul(y[j], invfact[j]) : fr_zero();
 }
 // q[i] = i < cnt ? P[top - i] : 0, i < total
 __global__ void __launch_bounds__(256) k_rev_take(Fr* __restrict__ q, const Fr* __restrict__ P, u64 top, u64 cnt, u64 total) {
