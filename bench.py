@@ -222,7 +222,7 @@ def main():
             },
             "result_affine_hex": result.hex()[:32] + "...",
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the one-GPU run only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log2)
         print(json.dumps(line))
     if dist is not None:
