@@ -925,7 +925,7 @@ struct Fp2s {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline int pair_lane() { return (int)(threadIdx.x & 1u); }
-__device__ inline i32 pair_swap(i32 x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); }
+__device__ inline i32 pair_swap(i32 x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, false); }
 #else  // host pass: never executed, present so that __device__ code parses
 PS_HD inline int pair_lane() { return 0; }
 PS_HD inline i32 pair_swap(i32 x) { return x; }

@@ -1,5 +1,9 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Host-side cost of one MSM call: time to enqueue (launch), GPU wait, host fold.  Run on the GPU box."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from playsnark_amd import api
 ctx = api.Context(0)
