@@ -185,7 +185,7 @@ def main():
         line = {
             "metric": "%s scalar-muls/s (Pippenger MSM, 2^%d pts per GPU)" % (args.group.upper(), args.log2n),
             "value": value,
-            "unit": "G1 scalar-muls/s",
+            "unit": "%s scalar-muls/s" % args.group.upper(),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
