@@ -93,7 +93,8 @@ int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, siz
  * may be pending on a context (PS_ERR_ARG beyond that): each runs on its own internal stream and
  * workspace, the accumulations chained in launch order, so a caller that keeps the queue full
  * (launch i+2, then finish i) hides each sum's sort and its latency-bound tail -- bucket fix-up,
- * reduction, host fold -- under its neighbours' accumulations. */
+ * reduction, host fold -- under its neighbours' accumulations.  The one-call forms (ps_msm, ps_msm_be32,
+ * ps_msm_i64, ps_msm_multi, the provers) need an empty queue (PS_ERR_ARG otherwise). */
 #define PS_MSM_QUEUE 3
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);

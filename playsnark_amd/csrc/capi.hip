@@ -831,6 +831,7 @@ extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
 }
 
 extern "C" int ps_msm(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, uint8_t* out) {
+    if (c && c->q_len) return fail(PS_ERR_ARG, "ps_msm: sums are pending on this context (ps_msm_finish them first)");
     int rc = ps_msm_launch(c, pts, sc);
     if (rc) return rc;
     return ps_msm_finish(c, out);

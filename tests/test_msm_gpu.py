@@ -277,6 +277,11 @@ def test_two_sums_in_flight_fifo(ps_api, ctx, co, pr):
             finished += 1
     with pytest.raises(ps_api.PlaysnarkError):
         ps_api.msm_finish(ctx, ps_api.G1)
+    # the one-call form would pop somebody else's result: refused while sums are pending
+    ps_api.msm_launch(ctx, jobs[0][1], jobs[0][2])
+    with pytest.raises(ps_api.PlaysnarkError):
+        jobs[1][2].BlindEval(jobs[1][1])
+    assert ps_api.msm_finish(ctx, jobs[0][0]) == jobs[0][3]
 
 
 def test_msm_multi_limits(ps_api, ctx, co, pr):
