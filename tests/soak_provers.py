@@ -1,6 +1,7 @@
 """Soak run for the multi-stream paths (pending-sum queue, multi-array sums, both provers): the same
 small jobs repeated, every result compared with the first iteration's.  Prints a line every 50
-iterations.  Usage (GPU box): python tools/soak_provers.py [iterations]"""
+iterations.  Not collected by pytest (no test_ prefix); lives under tests/ because it builds its inputs
+with the oracle.  Usage (GPU box): python tests/soak_provers.py [iterations]"""
 import os
 import sys
 import time
