@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 SEED = 0x706C6179736E61726B & 0xFFFFFFFFFFFFFFFF  # "playsnark"
+MAD_PEAK_PER_S = 2.82e13  # measured v_mad_u64_u32 lane-ops/s, profiles/r01_microbench_valu.txt
+MADS_PER_MIXED_ADD = {"g1": 3542, "g2": 2 * 5488}  # 8M+2S: 6*392 + 588 + 2*301; G2: (8*588 + 2*392) per lane of a pair
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SCALAR_MUL = 96 + 32                    # one affine G1 point + one scalar
 
@@ -218,6 +220,15 @@ def main():
                 "kernel_ms_one_at_a_time": single_acc_ms,
                 "frac_one_at_a_time": (n * BYTES_PER_SCALAR_MUL / (single_acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if single_acc_ms > 0 else 0.0,
                 "traffic": traffic,
+                # the roofline that actually binds: v_mad_u64_u32 issue rate, measured on
+                # this chip by tools/microbench_valu.hip; one mixed addition = 3 542 multiply-adds (G1)
+                "int_alu": {
+                    "mads_per_launch": info["entries"] * MADS_PER_MIXED_ADD[args.group],
+                    "peak_mads_per_s": MAD_PEAK_PER_S,
+                    "frac": info["entries"] * MADS_PER_MIXED_ADD[args.group] / (acc_ms * 1e-3) / MAD_PEAK_PER_S if acc_ms > 0 else 0.0,
+                    "frac_one_at_a_time": info["entries"] * MADS_PER_MIXED_ADD[args.group] / (single_acc_ms * 1e-3) / MAD_PEAK_PER_S
+                    if single_acc_ms > 0 else 0.0,
+                },
                 "note": "integer-ALU bound by construction (SURVEY 8d): see DESIGN.md for the v_mad_u64_u32 roofline",
             },
             "result_affine_hex": result.hex()[:32] + "...",
