@@ -408,7 +408,30 @@ static inline hipError_t quotient_from_AB(const NttTables& tabs, hipStream_t st,
 
 // Build every per-n table.  Host arithmetic is limited to the factorial table (n' field
 // multiplications and one inversion, with the library's own host-compiled field code).
-static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTables& qt, u64 n) {
+// j! and 1/j! for j < 2np, and v_j = (-1)^j / j! for j < np (host arithmetic: 4np multiplications, 1 inversion)
+struct FactTables {
+    std::vector<Fr> fact, inv, v;
+};
+static inline u64 qap_np(u64 n) { return 1ull << ilog2_ceil(n < 64 ? 64 : n); }
+static inline FactTables fact_tables(u64 np) {
+    FactTables t;
+    const u64 nf = 2 * np;
+    t.fact.resize(nf); t.inv.resize(nf); t.v.resize(np);
+    Fr f = fr_one();
+    for (u64 j = 0; j < nf; j++) {
+        if (j > 0) f = fr_mul(f, fr_from_u64(j));
+        t.fact[j] = f;
+    }
+    Fr finv = fr_inv(t.fact[nf - 1]);
+    for (u64 j = nf; j-- > 0;) {  // walk down: 1/(j-1)! = (1/j!) * j
+        t.inv[j] = finv;
+        if (j > 0) finv = fr_mul(finv, fr_from_u64(j));
+    }
+    for (u64 j = 0; j < np; j++) t.v[j] = (j & 1) ? fr_neg(t.inv[j]) : t.inv[j];
+    return t;
+}
+
+static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTables& qt, u64 n, const FactTables* ft = nullptr) {
     qt.n = n;
     int lg = ilog2_ceil(n < 64 ? 64 : n);
     qt.lognp = lg;
@@ -430,24 +453,14 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.pb, big));
     QT_TRY(qt_alloc(qt, &qt.z, n + 1));
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
-    // ---- factorials up to 2np - 1 (host) ----
+    // ---- factorials up to 2np - 1 (host; ps_qap_create computes them on a thread of its own) ----
     {
+        FactTables local;
+        if (!ft) { local = fact_tables(np); ft = &local; }
         const u64 nf = 2 * np;
-        std::vector<Fr> inv(nf), v(np), fact(nf);
-        Fr f = fr_one();
-        for (u64 j = 0; j < nf; j++) {
-            if (j > 0) f = fr_mul(f, fr_from_u64(j));
-            fact[j] = f;
-        }
-        Fr finv = fr_inv(fact[nf - 1]);
-        for (u64 j = nf; j-- > 0;) {  // walk down: 1/(j-1)! = (1/j!) * j
-            inv[j] = finv;
-            if (j > 0) finv = fr_mul(finv, fr_from_u64(j));
-        }
-        for (u64 j = 0; j < np; j++) v[j] = (j & 1) ? fr_neg(inv[j]) : inv[j];
-        QT_TRY(hipMemcpyAsync(qt.invfact, inv.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
-        QT_TRY(hipMemcpyAsync(qt.fact2, fact.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
-        QT_TRY(hipMemcpyAsync(qt.t1, v.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.invfact, ft->inv.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.fact2, ft->fact.data(), sizeof(Fr) * nf, hipMemcpyHostToDevice, st));
+        QT_TRY(hipMemcpyAsync(qt.t1, ft->v.data(), sizeof(Fr) * np, hipMemcpyHostToDevice, st));
         QT_TRY(hipStreamSynchronize(st));
     }
     hipLaunchKernelGGL(k_fr_copy_pad, dim3(nblk(2 * np)), dim3(256), 0, st, qt.vhat, qt.t1, np, 2 * np);

@@ -31,6 +31,11 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     R = pr.R
     rng = pr.SplitMix64(SEED + 2020)
     t = {}
+    t_begin = time.time()
+
+    def progress(what):  # a line per stage: long runs (PS_SCALE_LOG2N >= 22) must not look hung
+        print(f"[scale 2^{log2n}] {what} at {time.time() - t_begin:.1f} s", flush=True)
+
     t0 = time.time()
     c, sol = rs.synthetic_circuit(n)
     # The reference splits the variables at diff = nbVars - nbIO (groth16.go:86, pinochio.go:122) and
@@ -43,6 +48,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     alpha, beta, delta, x, gamma = (rng.fr() for _ in range(5))
     u, v, w, zx = rs.var_poly_evals(c, x)
     t["host_circuit_and_setup_scalars_s"] = time.time() - t0
+    progress("circuit and setup scalars on the host")
 
     # ---- CRS on the device: NewGroth16TrustedSetup (groth16.go:64-101), toxic waste retained for the checks
     up = lambda vals: ps_api.Poly.upload(ctx, vals)
@@ -55,6 +61,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     tr, vk = ps_api.NewGroth16TrustedSetup(q, alpha, beta, delta, x, gamma)
     ctx.sync()
     t["device_setup_s"] = time.time() - t0
+    progress("QAP tables and Groth16 CRS on the device")
     # spot-check the device CRS against scalars recomputed on the host
     xi_s = _powers(x, n, 1, R)
     assert tr.Xi.download(5, 1) == one(co.G1, xi_s[5]) and tr.Xi2.download(n - 1, 1) == one(co.G2, xi_s[n - 1])
@@ -72,6 +79,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     proof = ps_api.Groth16Prove(tr, q, dsol, r, s)
     t["groth16_prove_s"] = time.time() - t0
     t["groth16_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
+    progress("Groth16 proof")
 
     # ---- TestGroth16ProofGen at full size ----
     t0 = time.time()
@@ -99,6 +107,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     res = (res + pr.fr_div(hx * zx % R, delta)) % R
     cd = (res + s * a + r * b - r * s % R * delta) % R
     assert proof.C == one(co.G1, cd)
+    progress("Groth16 discrete-log checks")
 
     # ---- PHGR13 on the same QAP (BASELINE config #5 shape): device setup, prove, discrete-log checks of
     # every proof element from the retained toxic waste (pinocchio_test.go:33-146), pairing verification
@@ -114,6 +123,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     pp = ps_api.PHGR13Prove(ek, q, dsol)
     t["phgr13_prove_s"] = time.time() - t0
     t["phgr13_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
+    progress("PHGR13 setup and proof")
     us, vs_, ws_, zs = rs.var_poly_evals(c, sp)
     ry = rv * rw % R
     dot = lambda ev: sum(e * si for e, si in zip(ev[diff:], sol[diff:])) % R
@@ -123,6 +133,7 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     assert pp.wss == one(co.G2, rw * Wm % R) and pp.wass == one(co.G1, rw * aw % R * Wm % R)
     assert pp.yss == one(co.G1, ry * Ym % R) and pp.yass == one(co.G1, ry * ay % R * Ym % R)
     assert pp.gz == one(co.G1, pbeta * (rv * Vm + rw * Wm + ry * Ym) % R)
+    progress("PHGR13 discrete-log checks")
     t0 = time.time()
     io = up(sol[:diff])
     io_arrays = (pvk.vs.slice(0, diff), pvk.ws.slice(0, diff), pvk.ys.slice(0, diff))
