@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<typename Fie
 constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to k_fixup_heavy
 
 template <class KF>
-__global__ void __launch_bounds__(256, 2) k_fixup(const u32* __restrict__ offs, u32 G, int M,
+__global__ void __launch_bounds__(256, 1) k_fixup(const u32* __restrict__ offs, u32 G, int M,
                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
@@ -485,7 +485,7 @@ constexpr int RED_SEG_LOG = 3;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
 
 template <class KF>
-__global__ void __launch_bounds__(256, 2) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+__global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                       u32 nseg_total, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs) {
     u32 idx = logical_tid<KF>();
