@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
     ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
                     help="sums kept in flight per GPU (k: step i+k-1 is enqueued before step i is folded)")
+    ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform",
+                    help="uniform: 255-bit scalars (the headline); witness: int64 values as the reference's Vector holds "
+                         "them -- small, a tenth zeros, a tenth ones, a quarter negative (SURVEY 8d, regime ii)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (gloo + PS_BENCH_DEVICE=0 rehearses the multi-rank "
                          "path on a one-GPU box; the driver's runs use nccl = RCCL)")
@@ -129,7 +132,18 @@ def main():
     a = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 1000 + rank).tobytes())
     gid = api.G1 if args.group == "g1" else api.G2
     points = api.Points.from_scalars(ctx, gid, a)
-    scalars = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 2000 + rank).tobytes())
+    if args.scalars == "uniform":
+        scalars = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 2000 + rank).tobytes())
+    else:
+        import numpy as np
+
+        rs = np.random.RandomState((SEED + 3000 + rank) % (1 << 32))
+        w = rs.randint(0, 1 << 40, size=n, dtype=np.int64)
+        kind = rs.randint(0, 20, size=n)
+        w[kind < 2] = 0
+        w[(kind >= 2) & (kind < 4)] = 1
+        w[kind >= 15] *= -1
+        scalars = api.Poly.from_values(ctx, w.tolist())
     ctx.sync()
     msm = ShardedMsm(ctx, gid, dist, world)
 
@@ -199,7 +213,9 @@ def main():
             "dtype": "i32x14 (381-bit Fp, 28-bit unsaturated limbs, Montgomery)",
             "data": "synthetic",
             "config": {
-                "workload": "BLS12-381 G1 MSM, 2^%d points per GPU, uniform 255-bit scalars" % args.log2n,
+                "workload": "BLS12-381 %s MSM, 2^%d points per GPU, %s" % (
+                    args.group.upper(), args.log2n,
+                    "uniform 255-bit scalars" if args.scalars == "uniform" else "int64 witness scalars (zeros, ones, negatives)"),
                 "window_bits": c,
                 "windows": W,
                 "slice": info["slice"],

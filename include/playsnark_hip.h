@@ -70,7 +70,9 @@ void ps_points_free(ps_points* p);
 
 /* ---- scalar vectors: Poly = []Element (algebra.go:89) / Vector = []Value (algebra.go:13) ---- */
 int ps_scalars_upload(ps_ctx* ctx, const uint8_t* be32, size_t n, ps_scalars** out);
-/* Value.ToFieldElement = SetInt64 (curve.go:17-19): negatives map to r - |v|. */
+/* Value.ToFieldElement = SetInt64 (curve.go:17-19): negatives map to r - |v|.  Sums over such a vector use
+ * the short scalar |v| (64 bits: a quarter of the windows) and, for a negative value, the negated point --
+ * the same group element for points of order r, which every CRS point is. */
 int ps_scalars_upload_i64(ps_ctx* ctx, const int64_t* v, size_t n, ps_scalars** out);
 /* Wrap n big-endian 32-byte scalars already resident in device memory (e.g. a torch tensor's
  * data_ptr()); the bytes are converted into a library-owned vector. */

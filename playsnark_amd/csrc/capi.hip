@@ -76,7 +76,7 @@ struct ps_ctx {
     hipEvent_t ev_acc_local = nullptr, ev_tail_done = nullptr;
     bool tail_used = false;
     // MSM workspace
-    DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy;
+    DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts;
     DevBuf staging;                  // byte staging for uploads / downloads
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -143,8 +143,9 @@ struct ps_scalars {
     size_t n;
     Storage* st;
     size_t first;
-    int max_bits;  // upper bound on the bit length of every element
+    int max_bits;  // upper bound on the bit length of every element (of |v| when neg_small)
     int device;
+    bool neg_small = false;  // int64 witness vector with negative values: elements are v or r - |v|, |v| < 2^64
 };
 
 static inline size_t point_bytes(int group) { return group == PS_G1 ? sizeof(Affine<Fp>) : sizeof(Affine<Fp2>); }
@@ -195,7 +196,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
-                      &c->segs, &c->wins, &c->heavy, &c->vals, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+                      &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
     if (c->g16_pa) ps_points_free(c->g16_pa);
@@ -284,7 +285,8 @@ extern "C" int ps_scalars_upload_i64(ps_ctx* c, const int64_t* v, size_t n, ps_s
     HIP_TRY(hipGetLastError());
     bool any_neg = false;
     for (size_t i = 0; i < n; i++) any_neg |= v[i] < 0;
-    (*out)->max_bits = any_neg ? 255 : 64;  // non-negative witnesses need only ceil(64/c) windows
+    (*out)->max_bits = 64;  // witnesses need only ceil(64/c) windows; negatives are folded onto -P (k_digits_grouped)
+    (*out)->neg_small = any_neg;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PS_OK;
 }
@@ -309,7 +311,7 @@ extern "C" int ps_scalars_slice(const ps_scalars* s, size_t first, size_t n, ps_
     if (!s || !out) return fail(PS_ERR_ARG, "ps_scalars_slice: NULL argument");
     if (first + n > s->n) return fail(PS_ERR_LENGTH, "ps_scalars_slice: range out of bounds");
     s->st->refs++;
-    *out = new ps_scalars{n, s->st, s->first + first, s->max_bits, s->device};
+    *out = new ps_scalars{n, s->st, s->first + first, s->max_bits, s->device, s->neg_small};
     return PS_OK;
 }
 extern "C" void ps_scalars_free(ps_scalars* s) {
@@ -568,8 +570,8 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         while ((pl.NB >> bin_shift) > (u32)DIGITS_BINS) bin_shift++;
         dim3 grid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
         hipLaunchKernelGGL(k_digits_grouped, grid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, scalars_ptr(sc),
-                           (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, (u32*)c->counts.p, (u32*)c->keys.p, (u32*)c->vals.p,
-                           (u32*)c->ranks.p);
+                           (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, sc->neg_small ? 1 : 0, (u32*)c->counts.p, (u32*)c->keys.p,
+                           (u32*)c->vals.p, (u32*)c->ranks.p);
     }
     PS_STAGE_MARK();  // 1: after memset + digits
     hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
@@ -609,7 +611,10 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
     if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
-    if ((rc = wc->heavy.ensure(4 * (max_heavy + 1)))) return rc;
+    // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
+    if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
+    const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
+    if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
     if (sizeof(Xyzz<F>) * (size_t)pl.W > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
@@ -628,9 +633,16 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
     hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
-    hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
-                       (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (const u32*)wc->heavy.p,
-                       (const u32*)wc->heavy.p + 1);
+    {
+        const u32* hcount = (const u32*)wc->heavy.p;
+        const u32* hlist = hcount + 1;
+        u32* job_base = (u32*)wc->heavy.p + 1 + max_heavy;
+        hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, hcount, hlist, job_base);
+        hipLaunchKernelGGL(k_fixup_heavy_part<KF>, dim3(1024), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
+                           (const Xyzz<F>*)wc->parts.p, hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
+        hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)wc->hparts.p,
+                           (Xyzz<F>*)wc->buckets.p, hcount, hlist, (const u32*)job_base);
+    }
     PS_STAGE_MARK();  // 6: after fixup
     {
         Xyzz<F>* accs = (Xyzz<F>*)wc->segs.p;

@@ -93,9 +93,9 @@ __device__ inline u32 wave_incl_scan(u32 v);
 struct DigitConst { u32 w[8]; };  // the constant C above
 
 __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
-                                                                   DigitConst cadd, int bin_shift, u32* __restrict__ counts,
-                                                                   u32* __restrict__ ent_key, u32* __restrict__ ent_val,
-                                                                   u32* __restrict__ ent_rank) {
+                                                                   DigitConst cadd, int bin_shift, int fold_neg,
+                                                                   u32* __restrict__ counts, u32* __restrict__ ent_key,
+                                                                   u32* __restrict__ ent_val, u32* __restrict__ ent_rank) {
     __shared__ u32 hist[DIGITS_BINS];
     __shared__ u32 wtot[DIGITS_THREADS / 64];
     extern __shared__ __align__(16) unsigned char dg_smem[];
@@ -119,6 +119,20 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
             const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
             uint4 a = sp[0], b = sp[1];
             k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+            // Witness vectors (Value.ToFieldElement, curve.go:17-19): a negative value v is stored as r - |v|.
+            // (r - |v|) P = -(|v| P) for a point of order r, so the short scalar |v| is used with the point
+            // negated and the vector keeps its few windows.  Such an element is recognised by its top word.
+            u32 flip = 0;
+            if (fold_neg && k[7] != 0) {
+                u32 borrow = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    u64 t = (u64)FrParams::mod(q) - k[q] - borrow;
+                    k[q] = (u32)t;
+                    borrow = (u32)(t >> 63);
+                }
+                flip = 0x80000000u;
+            }
             u32 carry = 0;  // k' = k + C
 #pragma unroll
             for (int q = 0; q < 8; q++) {
@@ -132,7 +146,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
             int d = top ? (int)raw : (int)raw - (int)NB;
             if (d != 0) {
                 u32 mag = d < 0 ? (u32)(-d) : (u32)d;
-                code = (mag - 1u) | (d < 0 ? 0x80000000u : 0u);
+                code = (mag - 1u) | ((d < 0 ? 0x80000000u : 0u) ^ flip);
                 atomicAdd(&hist[(mag - 1u) >> bin_shift], 1u);
             }
         }
@@ -413,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<typename Fie
 // ---------------------------------------------------------------------------------------
 // 5. fix-up of buckets cut by slice boundaries
 // ---------------------------------------------------------------------------------------
-constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to k_fixup_heavy
+constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to the heavy-bucket kernels
 
 template <class KF>
 __global__ void __launch_bounds__(256, 1) k_fixup(const u32* __restrict__ offs, u32 G, int M,
@@ -440,31 +454,97 @@ __global__ void __launch_bounds__(256, 1) k_fixup(const u32* __restrict__ offs, 
     st_xyzz<KF>(&buckets[g], acc);
 }
 
-// Heavy buckets (skewed scalars): the partial slots of slices t0..t1 are summed by a whole
-// workgroup -- strided serial sums, then an LDS tree -- so the dependency chain is
-// (t1-t0)/256 + 8 additions instead of t1-t0.
+// Heavy buckets (skewed scalars: a witness that is half ones puts n/2 entries into one bucket).  The
+// partial slots of the slices t0..t1 of such a bucket are summed in two levels: the slices are cut into
+// jobs of HEAVY_CHUNK, any workgroup takes any job (strided serial sums, then an LDS tree), and a last
+// kernel adds up the job results of each bucket.  The dependency chain is HEAVY_CHUNK/256 + 8 additions
+// per level whatever the skew, and a single enormous bucket still uses the whole chip.
+constexpr u32 HEAVY_CHUNK = 1024;
+
+// job_base[h] = number of jobs of the heavy buckets before h; job_base[nheavy] = total.  One workgroup.
+__global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs, int M, const u32* __restrict__ heavy_count,
+                                                    const u32* __restrict__ heavy_list, u32* __restrict__ job_base) {
+    __shared__ u32 wsum[4];
+    const u32 nheavy = *heavy_count;
+    const u32 tid = threadIdx.x;
+    u32 running = 0;
+    for (u32 base = 0; base < nheavy; base += 256) {
+        const u32 h = base + tid;
+        u32 cnt = 0;
+        if (h < nheavy) {
+            const u32 g = heavy_list[h];
+            const u32 t0 = offs[g] / (u32)M, t1 = (offs[g + 1] - 1) / (u32)M;
+            cnt = (t1 - t0 + HEAVY_CHUNK) / HEAVY_CHUNK;  // ceil((t1 - t0 + 1) / CHUNK)
+        }
+        u32 inc = wave_incl_scan(cnt);
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        __syncthreads();
+        u32 before = 0, tile = 0;
+        for (u32 q = 0; q < 4; q++) {
+            if (q < (tid >> 6)) before += wsum[q];
+            tile += wsum[q];
+        }
+        if (h < nheavy) job_base[h] = running + before + inc - cnt;
+        running += tile;
+        __syncthreads();
+    }
+    if (tid == 0) job_base[nheavy] = running;
+}
+
 template <class KF>
-__global__ void __launch_bounds__(256) k_fixup_heavy(const u32* __restrict__ offs, int M,
-                                                     const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
-                                                     Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
-                                                     const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list) {
+__global__ void __launch_bounds__(256) k_fixup_heavy_part(const u32* __restrict__ offs, int M,
+                                                          const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
+                                                          const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
+                                                          const u32* __restrict__ job_base,
+                                                          Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
     const u32 nheavy = *heavy_count;
-    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const u32 g = heavy_list[h];
+    if (nheavy == 0) return;
+    const u32 njobs = job_base[nheavy];
+    for (u32 j = blockIdx.x; j < njobs; j += gridDim.x) {
+        u32 lo_h = 0, hi_h = nheavy;  // job_base[lo_h] <= j < job_base[hi_h]
+        while (hi_h - lo_h > 1) {
+            u32 mid = (lo_h + hi_h) >> 1;
+            if (job_base[mid] <= j) lo_h = mid; else hi_h = mid;
+        }
+        const u32 g = heavy_list[lo_h];
         const u32 lo = offs[g], hi = offs[g + 1];
         const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
+        const u32 ts = t0 + (j - job_base[lo_h]) * HEAVY_CHUNK;
+        const u32 te = (t1 - ts >= HEAVY_CHUNK) ? ts + HEAVY_CHUNK - 1 : t1;
         Xyzz<KF> acc = xyzz_identity<KF>();
-        for (u32 t = t0 + logical_local<KF>(); t <= t1; t += logical_block<KF>()) {
+        for (u32 t = ts + logical_local<KF>(); t <= te; t += logical_block<KF>()) {
             u32 slice_start = t * (u32)M;
             u32 rs = lo > slice_start ? lo : slice_start;
             Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
             xyzz_add_inl<KF>(acc, part);
         }
         block_tree_sum<KF>(sm, acc);
-        if (logical_local<KF>() == 0) st_xyzz<KF>(&buckets[g], ld_xyzz<KF>(&sm[0]));
+        if (logical_local<KF>() == 0) st_xyzz<KF>(&hparts[j], ld_xyzz<KF>(&sm[0]));
+        __syncthreads();
+    }
+}
+
+template <class KF>
+__global__ void __launch_bounds__(256) k_fixup_heavy(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts,
+                                                     Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                     const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
+                                                     const u32* __restrict__ job_base) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
+    const u32 nheavy = *heavy_count;
+    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const u32 j0 = job_base[h], j1 = job_base[h + 1];
+        Xyzz<KF> acc = xyzz_identity<KF>();
+        for (u32 j = j0 + logical_local<KF>(); j < j1; j += logical_block<KF>()) {
+            Xyzz<KF> part = ld_xyzz<KF>(&hparts[j]);
+            xyzz_add_inl<KF>(acc, part);
+        }
+        block_tree_sum<KF>(sm, acc);
+        if (logical_local<KF>() == 0) st_xyzz<KF>(&buckets[heavy_list[h]], ld_xyzz<KF>(&sm[0]));
         __syncthreads();
     }
 }

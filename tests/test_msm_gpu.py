@@ -107,6 +107,13 @@ def test_blind_eval_int64_witness_scalars(ps_api, ctx, co, pr, name):
     pts = ps_api.Points.upload(ctx, gid, raw)
     got = ps_api.Poly.from_values(ctx, vals).BlindEval(pts)
     assert got == og.to_b(og.blind_eval_i64(vals, raw))
+    # negatives are folded onto the negated point: the vector keeps the short-scalar plan
+    assert ctx.last_msm_info()["windows"] * ctx.last_msm_info()["window_bits"] < 128
+    extremes = [-(1 << 63), (1 << 63) - 1, -1, 1, 0, -(1 << 63) + 1] + [-(int(rng.next() % (1 << 62))) for _ in range(n - 6)]
+    got = ps_api.Poly.from_values(ctx, extremes).BlindEval(pts)
+    assert got == og.to_b(og.blind_eval_i64(extremes, raw))
+    sl = ps_api.Poly.from_values(ctx, vals).slice(3, 50)  # a view keeps the folding
+    assert sl.BlindEval(pts.slice(3, 50)) == og.to_b(og.blind_eval_i64(vals[3:53], raw[3 * og.nb : 53 * og.nb]))
     # all non-negative: the short-scalar plan (fewer windows) must give the same point
     pos = [abs(v) for v in vals]
     got = ps_api.Poly.from_values(ctx, pos).BlindEval(pts)
