@@ -283,3 +283,31 @@ def test_phgr13_arrays_of_unequal_length(ps_api, ctx, co, pr):
     proof = ps_api.PHGR13Prove(_phgr13_ek(ps_api, ctx, ek), q, ps_api.Poly.upload(ctx, sol))
     for f in ps_api.PHGR13Proof.FIELDS:
         assert getattr(proof, f) == getattr(want, f), f
+
+
+def test_groth16_int64_witness_with_negative_values(ps_api, ctx, co, pr):
+    """The reference's Vector is []int (algebra.go:13): a witness uploaded as int64 -- negative values
+    included -- keeps the short-scalar plan; Groth16Prove then sums its NioLP part separately and the
+    three proof elements are still byte-identical to the oracle (which works with the values mod r)."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 4321)
+    c, sol = rs.synthetic_circuit(8, x0=pr.R - 3)  # x = -3: every wire is a small signed integer
+    wit = [v if v < pr.R // 2 else v - pr.R for v in sol]
+    assert min(wit) < 0 and max(abs(v) for v in wit) < 1 << 62
+    for nb_io in (3, c.nbVars - 3):  # both sides of the reference's `diff` split carry witness values
+        cc = rs.SparseR1CS(c.nbVars, nb_io, c.left, c.right, c.out)
+        tox = [rng.fr() for _ in range(5)]
+        r, s = rng.fr(), rng.fr()
+        want = rs.groth16_prove(rs.groth16_setup(cc, *tox), cc, sol, r, s)
+        q = _upload_circuit(ps_api, ctx, cc)
+        tr, _ = ps_api.NewGroth16TrustedSetup(q, *tox)
+        proof = ps_api.Groth16Prove(tr, q, ps_api.Poly.from_values(ctx, wit), r, s)
+        assert (proof.A, proof.B, proof.C) == (want.A, want.B, want.C)
+        # PHGR13 on the same witness: all seven sums take the short plan
+        ptox = [rng.fr() for _ in range(8)]
+        pwant = rs.phgr13_prove(rs.phgr13_setup(cc, *ptox).EK, cc, sol)
+        ek, _ = ps_api.NewPHGR13TrustedSetup(q, *ptox)
+        pp = ps_api.PHGR13Prove(ek, q, ps_api.Poly.from_values(ctx, wit))
+        for f in ps_api.PHGR13Proof.FIELDS:
+            assert getattr(pp, f) == getattr(pwant, f), f
