@@ -129,6 +129,20 @@ def var_poly_evals(c: SparseR1CS, x: int):
     return res[0], res[1], res[2], zx
 
 
+def bit_circuit(n_gates: int, seed: int = 7):
+    """n booleanity gates b_i * b_i = b_i over n + 1 variables [const, b_1 .. b_n] (nbIO = nbVars - 1 puts the
+    reference's `diff` split right after the constant): the commonest gate of real circuits, and a witness
+    that fits the reference's Vector = []int (algebra.go:13) -- random bits.  Returns (circuit, int witness)."""
+    rng = pr.SplitMix64(seed)
+    bits, word = [], 0
+    for i in range(n_gates):
+        if i % 64 == 0:
+            word = rng.next()
+        bits.append((word >> (i % 64)) & 1)
+    rows = [[(1 + i, 1)] for i in range(n_gates)]
+    return SparseR1CS(n_gates + 1, n_gates, rows, rows, rows), [1] + bits
+
+
 class Bag:
     def __init__(self, **kw):
         self.__dict__.update(kw)

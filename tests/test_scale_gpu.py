@@ -142,3 +142,52 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     pp.gz = one(co.G1, 12345)
     assert not ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, pp, io)
     print("SCALE " + json.dumps({"log2n": log2n, "n_vars": m, **{k: (round(val, 4) if isinstance(val, float) else val) for k, val in t.items()}}))
+
+
+def test_provers_on_a_booleanity_circuit_with_an_int64_witness(ps_api, ctx, co, pr):
+    """The regime the reference itself lives in: Vector = []int (algebra.go:13).  2^k booleanity gates
+    b*b = b, a witness of random bits uploaded as int64: the solution sums take the short-scalar plan
+    (and the heavy-bucket path: half the entries fall into one bucket).  Checks: both proofs are accepted
+    by the verifiers (pairings), rejected when tampered with, and byte-identical to the proofs obtained
+    from the same witness uploaded as 32-byte field elements (the 255-bit plan)."""
+    from oracle import restate as rs
+
+    log2n = int(os.environ.get("PS_SCALE_LOG2N", "16"))
+    n = 1 << log2n
+    rng = pr.SplitMix64(SEED + 3030)
+    c, wit = rs.bit_circuit(n)
+    diff = c.nbVars - c.nbIO
+    q = ps_api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+    tox = [rng.fr() for _ in range(5)]
+    ptox = [rng.fr() for _ in range(8)]
+    tr, vk = ps_api.NewGroth16TrustedSetup(q, *tox)
+    ek, pvk = ps_api.NewPHGR13TrustedSetup(q, *ptox)
+    sol_i64 = ps_api.Poly.from_values(ctx, wit)
+    sol_fr = ps_api.Poly.upload(ctx, wit)
+    r, s = rng.fr(), rng.fr()
+    t = {}
+    out = {}
+    for name, sol in (("int64", sol_i64), ("fr", sol_fr)):
+        ps_api.Groth16Prove(tr, q, sol, r, s)  # warm-up
+        t0 = time.time()
+        g = ps_api.Groth16Prove(tr, q, sol, r, s)
+        t[f"groth16_prove_{name}_s"] = time.time() - t0
+        ps_api.PHGR13Prove(ek, q, sol)
+        t0 = time.time()
+        p = ps_api.PHGR13Prove(ek, q, sol)
+        t[f"phgr13_prove_{name}_s"] = time.time() - t0
+        out[name] = (g, p)
+    g, p = out["int64"]
+    g2, p2 = out["fr"]
+    assert (g.A, g.B, g.C) == (g2.A, g2.B, g2.C)
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(p, f) == getattr(p2, f), f
+    io = ps_api.Poly.from_values(ctx, wit[:diff])
+    verify16 = lambda proof: ps_api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, vk["Gamma"], tr.Delta2, vk["IoLP"], proof, io)
+    assert verify16(g)
+    assert not verify16(ps_api.Groth16Proof(r, s, g.A, g.B, co.G1.to_b(co.G1.mul(777))))
+    io_arrays = (pvk.vs.slice(0, diff), pvk.ws.slice(0, diff), pvk.ys.slice(0, diff))
+    assert ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, p, io)
+    p.vss = co.G1.to_b(co.G1.mul(777))
+    assert not ps_api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, p, io)
+    print("SCALE-BITS " + json.dumps({"log2n": log2n, **{k: round(v, 4) for k, v in t.items()}}))
