@@ -60,3 +60,74 @@ class ShardedMsm:
             if on_step:
                 on_step()
         return result
+
+
+class ShardedPHGR13:
+    """PHGR13Prove (pinochio.go:207-254) with its sums sharded over the ranks (BASELINE config #5).
+
+    Every sum of the proof is linear in (points, scalars), so rank g takes the index range
+    shard_range(len, g, G) of each evaluation-key array with the matching range of the scalars:
+        hs                     h[range] over gsi[range]                      (pinochio.go:218)
+        vss .. yass, gz        solution[diff:][range] over the nine arrays   (pinochio.go:231-242),
+                               one digit sort for all of them (ps_msm_multi)
+    and produces nine partial points; one all_gather of 8 x 96 + 192 bytes per rank and a local fold
+    give every rank the proof.  The quotient h is not sharded (its NTTs would need an all-to-all): each
+    rank computes it from the full witness -- deterministic, so identical everywhere.
+    """
+
+    G1_FIELDS = ("vss", "yss", "vass", "wass", "yass", "hs", "gz")
+
+    def __init__(self, ctx, dist=None, world: int = 1, rank: int = 0):
+        self.ctx, self.dist, self.world, self.rank = ctx, dist, world, rank
+
+    def partials(self, ek: "api.PHGR13EvalKey", qap: "api.QAP", solution: "api.Poly", rank=None) -> dict:
+        """This rank's share of every proof element (affine bytes; the identity for an empty range)."""
+        rank = self.rank if rank is None else rank
+        ctx = self.ctx
+        h = qap.Quotient(solution)  # raises Apocalypse exactly as the unsharded prover
+        first, cnt = shard_range(len(h), rank, self.world)
+        out = {"hs": h.slice(first, cnt).BlindEval(ek.gsi.slice(first, cnt))}
+        diff = qap.nbVars - qap.nbIO
+        nn = len(ek.vs)
+        first, cnt = shard_range(nn, rank, self.world)
+        names = ("vs", "ws", "ys", "vas", "was", "yas", "vbs", "wbs", "ybs")
+        arrays = [getattr(ek, f).slice(first, cnt) for f in names]
+        sums = api.msm_multi(ctx, arrays, solution.slice(diff + first, cnt))
+        by = dict(zip(names, sums))
+        out.update(vss=by["vs"], wss=by["ws"], yss=by["ys"], vass=by["vas"], wass=by["was"], yass=by["yas"])
+        out["gz"] = api.points_sum(api.G1, by["vbs"] + by["wbs"] + by["ybs"])  # pinochio.go:242
+        return out
+
+    @staticmethod
+    def fold(parts: list) -> "api.PHGR13Proof":
+        """Element-wise sum of the ranks' partial proofs."""
+        raw = api._lib.Phgr13Proof()
+        for f in api.PHGR13Proof.FIELDS:
+            grp = api.G2 if f == "wss" else api.G1
+            total = api.points_sum(grp, b"".join(p[f] for p in parts))
+            api.C.memmove(getattr(raw, f), total, len(total))
+        return api.PHGR13Proof(raw)
+
+    def prove(self, ek, qap, solution) -> "api.PHGR13Proof":
+        mine = self.partials(ek, qap, solution)
+        if self.dist is None or self.world == 1:
+            return self.fold([mine])
+        import torch
+
+        order = api.PHGR13Proof.FIELDS
+        blob = b"".join(mine[f] for f in order)
+        backend = self.dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+        gathered = torch.empty(self.world * len(blob), dtype=torch.uint8, device=dev)
+        self.dist.all_gather_into_tensor(gathered, t)
+        flat = gathered.cpu().numpy().tobytes()
+        parts = []
+        for g in range(self.world):
+            chunk, off, p = flat[g * len(blob):(g + 1) * len(blob)], 0, {}
+            for f in order:
+                nb = 192 if f == "wss" else 96
+                p[f] = chunk[off:off + nb]
+                off += nb
+            parts.append(p)
+        return self.fold(parts)

@@ -76,3 +76,45 @@ def test_pipelined_runner_keeps_depth_and_order(monkeypatch):
             assert last == steps.to_bytes(4, "big")
             if steps >= depth:
                 assert max(p for _, _, p in log) == depth
+
+
+PHGR13_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from oracle import pyref as pr, restate as rs
+from playsnark_amd import api
+from playsnark_amd.dist import ShardedPHGR13
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ctx = api.Context(0)  # rehearsal: every rank on the one GPU of the box
+rng = pr.SplitMix64(99)
+c, sol = rs.synthetic_circuit(60)
+c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
+q = api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+ek, vk = api.NewPHGR13TrustedSetup(q, *[rng.fr() for _ in range(8)])
+sol_dev = api.Poly.upload(ctx, sol)
+whole = api.PHGR13Prove(ek, q, sol_dev)
+got = ShardedPHGR13(ctx, dist, world, rank).prove(ek, q, sol_dev)
+for f in api.PHGR13Proof.FIELDS:
+    assert getattr(got, f) == getattr(whole, f), (rank, f)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_sharded_phgr13_two_ranks_on_one_gpu(tmp_path):
+    """Two processes (gloo for the exchange, both on GPU 0): each proves its index ranges, the
+    all_gather + fold gives every rank the unsharded proof."""
+    script = tmp_path / "worker.py"
+    script.write_text(PHGR13_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29618", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 2

@@ -311,3 +311,27 @@ def test_groth16_int64_witness_with_negative_values(ps_api, ctx, co, pr):
         pp = ps_api.PHGR13Prove(ek, q, ps_api.Poly.from_values(ctx, wit))
         for f in ps_api.PHGR13Proof.FIELDS:
             assert getattr(pp, f) == getattr(pwant, f), f
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_phgr13_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
+    """BASELINE config #5 shape on one GPU: the index-range shares that `world` ranks would compute
+    (playsnark_amd.dist.ShardedPHGR13.partials), folded, are the unsharded proof byte for byte -- also
+    when some ranks get an empty range (8 ranks, 5-element arrays)."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedPHGR13
+
+    rng = pr.SplitMix64(SEED + 555 + world)
+    c, sol = rs.synthetic_circuit(41)
+    setups = [(c, "few"), (rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out), "many")]
+    if world == 8:
+        setups.append((rs.SparseR1CS(c.nbVars, 5, c.left, c.right, c.out), "five"))
+    for cc, _ in setups:
+        q = _upload_circuit(ps_api, ctx, cc)
+        ek, _vk = ps_api.NewPHGR13TrustedSetup(q, *[rng.fr() for _ in range(8)])
+        sol_dev = ps_api.Poly.upload(ctx, sol)
+        whole = ps_api.PHGR13Prove(ek, q, sol_dev)
+        sh = ShardedPHGR13(ctx, None, world, 0)
+        folded = sh.fold([sh.partials(ek, q, sol_dev, rank=g) for g in range(world)])
+        for f in ps_api.PHGR13Proof.FIELDS:
+            assert getattr(folded, f) == getattr(whole, f), f
