@@ -62,6 +62,9 @@ int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts,
  * reduce to this once the exponents are known. */
 int ps_points_from_scalars(ps_ctx* ctx, int group, const ps_scalars* k, ps_points** out);
 int ps_points_download(ps_ctx* ctx, const ps_points* p, size_t first, size_t n, uint8_t* out);
+/* Same with the output format chosen: PS_FMT_COMPRESSED gives the 48 / 96-byte form of MarshalBinary
+ * (pinochio.go:258-272), compressed on the GPU -- the at-rest form of key files. */
+int ps_points_download_fmt(ps_ctx* ctx, const ps_points* p, size_t first, size_t n, int fmt, uint8_t* out);
 size_t ps_points_len(const ps_points* p);
 int ps_points_group(const ps_points* p);
 /* A view of [first, first+n) sharing storage with `p` (index-range sharding, multi-GPU). */

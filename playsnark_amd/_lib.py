@@ -21,7 +21,7 @@ PS_G1, PS_G2 = 1, 2
 SYMBOLS = [
     "ps_last_error", "ps_version", "ps_device_count",
     "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream",
-    "ps_points_upload", "ps_points_from_scalars", "ps_points_download", "ps_points_len", "ps_points_group",
+    "ps_points_upload", "ps_points_from_scalars", "ps_points_download", "ps_points_download_fmt", "ps_points_len", "ps_points_group",
     "ps_points_slice", "ps_points_free",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
@@ -115,6 +115,7 @@ def _load():
     lib.ps_points_upload.argtypes = [vp, i, C.c_char_p, sz, i, pp]
     lib.ps_points_from_scalars.argtypes = [vp, i, vp, pp]
     lib.ps_points_download.argtypes = [vp, vp, sz, sz, C.c_char_p]
+    lib.ps_points_download_fmt.argtypes = [vp, vp, sz, sz, i, C.c_char_p]
     lib.ps_points_len.argtypes = [vp]
     lib.ps_points_group.argtypes = [vp]
     lib.ps_points_slice.argtypes = [vp, sz, sz, pp]

@@ -142,6 +142,41 @@ class Points:
         _check(lib.ps_points_download(self.ctx._h, self._h, first, n, buf))
         return buf.raw[: _WIRE[self.group] * n]
 
+    def download_compressed(self, first: int = 0, n: Optional[int] = None) -> bytes:
+        """kyber MarshalBinary form (ZCash compressed, 48 B G1 / 96 B G2), compressed on the GPU."""
+        n = len(self) - first if n is None else n
+        wb = _WIRE[self.group] // 2
+        buf = C.create_string_buffer(wb * max(n, 1))
+        _check(lib.ps_points_download_fmt(self.ctx._h, self._h, first, n, _lib.PS_FMT_COMPRESSED, buf))
+        return buf.raw[: wb * n]
+
+    # Flat key files (SURVEY 8 row f3; the reference has no persistence): a 16-byte header
+    # b"PSNK" | u8 version | u8 group | u8 format | u8 0 | u64 count (little-endian), then the points.
+    def save(self, path: str, compressed: bool = True):
+        import struct
+
+        fmt = _lib.PS_FMT_COMPRESSED if compressed else _lib.PS_FMT_AFFINE
+        with open(path, "wb") as f:
+            f.write(b"PSNK" + struct.pack("<BBBBQ", 1, self.group, fmt, 0, len(self)))
+            f.write(self.download_compressed() if compressed else self.download())
+
+    @classmethod
+    def load(cls, ctx: Context, path: str) -> "Points":
+        import struct
+
+        with open(path, "rb") as f:
+            head = f.read(16)
+            if len(head) != 16 or head[:4] != b"PSNK":
+                raise PlaysnarkError(-3, f"{path}: not a playsnark key file")
+            version, group, fmt, _, count = struct.unpack("<BBBBQ", head[4:])
+            if version != 1 or group not in (PS_G1, PS_G2) or fmt not in (_lib.PS_FMT_AFFINE, _lib.PS_FMT_COMPRESSED):
+                raise PlaysnarkError(-3, f"{path}: unsupported key file header")
+            wb = _WIRE[group] if fmt == _lib.PS_FMT_AFFINE else _WIRE[group] // 2
+            raw = f.read()
+        if len(raw) != wb * count:
+            raise PlaysnarkError(-1, f"{path}: {len(raw)} bytes of points, header says {count} x {wb}")
+        return cls.upload(ctx, group, raw, fmt)
+
     def slice(self, first: int, n: int) -> "Points":
         h = C.c_void_p()
         _check(lib.ps_points_slice(self._h, first, n, C.byref(h)))

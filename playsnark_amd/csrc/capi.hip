@@ -434,6 +434,29 @@ extern "C" int ps_points_download(ps_ctx* c, const ps_points* p, size_t first, s
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PS_OK;
 }
+extern "C" int ps_points_download_fmt(ps_ctx* c, const ps_points* p, size_t first, size_t n, int fmt, uint8_t* out) {
+    if (fmt == PS_FMT_AFFINE) return ps_points_download(c, p, first, n, out);
+    if (fmt != PS_FMT_COMPRESSED) return fail(PS_ERR_ARG, "ps_points_download_fmt: bad format");
+    if (!c || !p || (n && !out)) return fail(PS_ERR_ARG, "ps_points_download_fmt: NULL argument");
+    if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_download_fmt: range out of bounds");
+    if (!n) return PS_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t wb = wire_bytes(p->group) / 2;
+    int rc = c->staging.ensure(wb * n);
+    if (rc) return rc;
+    const char* src = (const char*)points_ptr(p) + first * point_bytes(p->group);
+    if (p->group == PS_G1)
+        hipLaunchKernelGGL(k_points_compress<Fp>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<Fp>*)src, (u32)n, (u32)wb,
+                           (uint8_t*)c->staging.p);
+    else
+        hipLaunchKernelGGL(k_points_compress<Fp2>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<Fp2>*)src, (u32)n, (u32)wb,
+                           (uint8_t*)c->staging.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->staging.p, wb * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PS_OK;
+}
 extern "C" size_t ps_points_len(const ps_points* p) { return p ? p->n : 0; }
 extern "C" int ps_points_group(const ps_points* p) { return p ? p->group : 0; }
 extern "C" int ps_points_slice(const ps_points* p, size_t first, size_t n, ps_points** out) {

@@ -809,6 +809,15 @@ PS_HD inline void compress_point(uint8_t* out, const Affine<Fp2>& a) {
     out[0] |= 0x80 | (fp_lex_larger(a.y) ? 0x20 : 0);
 }
 
+// out[stride * i ..] = ZCash compressed form of in[i] (what kyber's MarshalBinary emits)
+template <class F>
+__global__ void __launch_bounds__(256) k_points_compress(const Affine<F>* __restrict__ in, u32 n, u32 stride,
+                                                         uint8_t* __restrict__ out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    compress_point(out + (size_t)stride * i, in[i]);
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_points_decompress(const uint8_t* __restrict__ in, u32 n, u32 stride,
                                                            Affine<F>* __restrict__ out, u32* __restrict__ nbad) {

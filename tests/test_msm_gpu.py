@@ -5,6 +5,8 @@ Reference behaviour under test: Poly.BlindEval (algebra.go:348-359), its int64-s
 Method of the reference's own tests (algebra_test.go:21-35): compare against an independently
 computed group element.
 """
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -337,3 +339,33 @@ def test_pending_queue_random_schedule(ps_api, ctx, co, pr):
     while pending:
         j = pending.pop(0)
         assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3]
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_compressed_download_and_key_files(ps_api, ctx, co, pr, name, tmp_path):
+    """MarshalBinary form out of the GPU (pinochio.go:258-272): byte-equal to the oracle's compression,
+    identity included; a key file written in either form loads back to the same points; a damaged file
+    is refused."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 9500)
+    n = 300
+    raw = og.gen_points(rng.fr(), rng.fr(), n - 1) + og.to_b(None)
+    pts = ps_api.Points.upload(ctx, gid, raw)
+    compress = co.g1_compress if name == "g1" else co.g2_compress
+    want = b"".join(compress(p) for p in og.unpack(raw))
+    assert pts.download_compressed() == want
+    assert pts.download_compressed(7, 5) == want[7 * og.nb // 2 : 12 * og.nb // 2]
+    for compressed in (True, False):
+        path = str(tmp_path / f"key_{name}_{int(compressed)}.psnk")
+        pts.save(path, compressed=compressed)
+        assert os.path.getsize(path) == 16 + n * (og.nb // 2 if compressed else og.nb)
+        back = ps_api.Points.load(ctx, path)
+        assert back.group == gid and back.download() == raw
+    blob = bytearray(open(path, "rb").read())
+    blob[3] ^= 1
+    open(path, "wb").write(blob)
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.Points.load(ctx, path)
+    open(path, "wb").write(bytes(blob[:3]) + b"K" + bytes(blob[4:-1]))  # one byte short
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.Points.load(ctx, path)
