@@ -55,27 +55,64 @@ __device__ inline Fr fr_shfl(const Fr& v, int src) {  // broadcast of lane `src`
     return r;
 }
 
+// v * 2^-28 mod r (lazy): one Montgomery step.  r = 1 mod 2^28, so the digit is a negation and limb 0 of r
+// contributes just the digit itself.
+__device__ inline Fr fr_div_2p28(const Fr& v) {
+    Fr o;
+    i64 acc = (i64)v.l[0];
+    const i64 m = (i64)((0u - (u32)acc) & FP_MASK);
+    acc = (acc + m) >> 28;
+#pragma unroll
+    for (int i = 1; i < FR_L; i++) {
+        acc += (i64)v.l[i] + m * (i64)fr_mod28(i);
+        o.l[i - 1] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    o.l[FR_L - 1] = (i32)acc;
+    return o;
+}
+// (up - c * coef) * 2^-28 mod r for a plain integer c < 2^28: 10 + 10 multiply-adds instead of the 200 of a
+// full Montgomery product by the Montgomery form of c.
+__device__ inline Fr fr_sub_mul_small_div_2p28(const Fr& up, const Fr& coef, u32 c) {
+    Fr o;
+    const i64 cc = (i64)c;
+    i64 acc = (i64)up.l[0] - cc * (i64)coef.l[0];
+    const i64 m = (i64)((0u - (u32)acc) & FP_MASK);
+    acc = (acc + m) >> 28;
+#pragma unroll
+    for (int i = 1; i < FR_L; i++) {
+        acc += (i64)up.l[i] - cc * (i64)coef.l[i] + m * (i64)fr_mod28(i);
+        o.l[i - 1] = (i32)((u32)acc & FP_MASK);
+        acc >>= 28;
+    }
+    o.l[FR_L - 1] = (i32)acc;
+    return o;
+}
+
 // block b: N(x) = sum_{k=0..63} d[64b+k] * prod_{i=64b+1}^{64b+k} (x - (off + i)), in place.
 // Horner in the Newton basis: poly = poly*(x - (off+64b+k+1)) + d[64b+k], k = 63..0.
 // off = 0 for the QAP domain {1..n}; off = n for the nodes n+1.. of the h-only path.
-__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off) {
+// The nodes are small integers, so each step multiplies by a plain c < 2^28 and divides by 2^28 (one
+// Montgomery step, see above) instead of a full field multiplication.  To keep every term at the same
+// scale, d[64b+L] is divided by 2^28 once per step before it enters (lanes L < k in step k), so all terms
+// end with the factor 2^(-28*63); `unscale` = 2^(28*63) (Montgomery form) removes it.
+__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off, Fr unscale) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nblocks64) return;
     const u64 base = 64ull * wave;
-    const Fr mine = d[base + lane];
+    Fr mine = d[base + lane];
     Fr coef = fr_zero();
-    Fr c = fr_from_u64(off + base + 64);  // node of step k = 63
-    const Fr one = fr_one();
+    u32 c = (u32)(off + base + 64);  // node of step k = 63
     for (int k = 63; k >= 0; k--) {
         Fr up = fr_shfl_up1(coef);
         Fr dk = fr_shfl(mine, k);
-        coef = fr_sub(up, fr_mul(c, coef));
+        coef = fr_sub_mul_small_div_2p28(up, coef, c);
         if (lane == 0) coef = fr_add(coef, dk);
-        coef = fr_norm(coef);  // lazy: values grow by ~r per step (<= 70 r), limbs stay at class ~1
-        c = fr_norm(fr_sub(c, one));
+        if (lane < k) mine = fr_div_2p28(mine);
+        c -= 1;
     }
-    d[base + lane] = coef;
+    d[base + lane] = fr_mul(coef, unscale);
 }
 
 // block b: lower 64 coefficients of prod_{i=64b+1}^{64b+64} (x - (off + i))  (the x^64 term is implied)
@@ -315,7 +352,12 @@ static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
 // coefficients, in place
 static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, u64 np, int lognp, const std::vector<Fr*>& zhat,
                                             u64 off, Fr* data, Fr* scratch) {
-    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64), off);
+    Fr unscale = fr_from_u64(1ull << 28);  // 2^(28*63), Montgomery form
+    {
+        const Fr two28 = unscale;
+        for (int i = 1; i < 63; i++) unscale = fr_mul(unscale, two28);
+    }
+    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64), off, unscale);
     for (int logs = 7; logs <= lognp; logs++) {
         // scratch = NTT(upper halves of the nodes, zero-padded) * zhat ; data = lower halves + INTT(scratch):
         // prepare, multiply and combine ride on the first load / last store of the two transforms
