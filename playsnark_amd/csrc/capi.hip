@@ -661,7 +661,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         const u32* hlist = hcount + 1;
         u32* job_base = (u32*)wc->heavy.p + 1 + max_heavy;
         hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, hcount, hlist, job_base);
-        hipLaunchKernelGGL(k_fixup_heavy_part<KF>, dim3(1024), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
+        hipLaunchKernelGGL(k_fixup_heavy_part<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
                            (const Xyzz<F>*)wc->parts.p, hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
         hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)wc->hparts.p,
                            (Xyzz<F>*)wc->buckets.p, hcount, hlist, (const u32*)job_base);
