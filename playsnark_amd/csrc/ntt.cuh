@@ -11,7 +11,8 @@
 //     is a broadcast, not a gather;
 //   * the forward transform only ever *adds* a product to a value, so with the lazy Fr
 //     representation (field.cuh) values grow by ~r per stage and need no reduction at all; the
-//     inverse doubles per stage and is brought back by the 2^-k scaling at the end of each pass.
+//     inverse doubles per stage along the all-sums path; the factor is divided out by the last pass
+//     (and by an earlier one only if it would pass 2^16).
 // A transform of 2^p points is cut into ceil(p/8) passes; each pass stages a tile of 2^k rows x
 // COLS columns (2048 Fr = 80 KB) in LDS, runs k butterfly stages there, and touches HBM exactly
 // once for reading and once for writing.  Batched transforms (many blocks of 2^p points back to
@@ -76,7 +77,7 @@ struct NttFuse {
 
 template <bool INV>
 __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
-                                                  const Fr* __restrict__ tw, int log_tab, NttFuse fz) {
+                                                  const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
     const u32 COLS = 1u << logCols, rows = 1u << k;
@@ -188,10 +189,13 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
         }
         __syncthreads();
     }
+    // The inverse doubles along the all-sums path (a product pulls a value back under 2r, a sum does not);
+    // 2^16 r still fits the lazy limbs with room to spare (top limb < 2^20), so ntt_run asks for the
+    // scaling 2^-scale_log only in the last pass of a transform, or earlier for very long ones.
     Fr sc;
-    if (INV) {
+    if (INV && scale_log) {
 #pragma unroll
-        for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[k][j];
+        for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[scale_log][j];
     }
     for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
         u32 t, col;
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int 
         u64 q = q0 + col;
         u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
         Fr v = tile[t * COLS + col];
-        if (INV) v = fr_mul(v, sc);  // 2^-k of this pass; also pulls the doubled values back under ~r
+        if (INV && scale_log) v = fr_mul(v, sc);
         if (fz.st == NTT_ST_PLAIN) {
             data[addr] = v;
         } else if (fz.st == NTT_ST_MUL) {
@@ -251,7 +255,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     const int log_total = ilog2_ceil(total);
     int npass = (p + NTT_MAX_K - 1) / NTT_MAX_K;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
-    int done = 0;
+    int done = 0, unscaled = 0;  // unscaled: inverse stages whose factor 2 per stage has not been divided out yet
     for (int ps_i = 0; ps_i < npass; ps_i++) {
         int k = (p - done + (npass - ps_i) - 1) / (npass - ps_i);
         int logD = INV ? done : (p - done - k);
@@ -270,8 +274,16 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         fz.logs = fuse.logs;
         fz.cnt = fuse.cnt;
         fz.top = fuse.top;
+        // inverse: divide the doubling out in the last pass, and earlier only where the next pass would push
+        // the growth past 2^16 (the lazy top limb holds 2^16 r with room to spare)
+        int scale_log = 0;
+        if (INV) {
+            unscaled += k;
+            const int next_k = ps_i + 1 < npass ? (p - done - k + (npass - ps_i - 1) - 1) / (npass - ps_i - 1) : 0;
+            if (ps_i == npass - 1 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
+        }
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
-                           INV ? tb.inv : tb.fwd, tb.log_tab, fz);
+                           INV ? tb.inv : tb.fwd, tb.log_tab, fz, scale_log);
         done += k;
     }
     return hipGetLastError();
