@@ -369,3 +369,40 @@ def test_compressed_download_and_key_files(ps_api, ctx, co, pr, name, tmp_path):
     open(path, "wb").write(bytes(blob[:3]) + b"K" + bytes(blob[4:-1]))  # one byte short
     with pytest.raises(ps_api.PlaysnarkError):
         ps_api.Points.load(ctx, path)
+
+
+@pytest.mark.parametrize("name,log2n", [("g1", 20), ("g2", 18)])
+def test_full_size_properties_2pow20(ps_api, ctx, co, pr, name, log2n):
+    """BASELINE's full size (2^20 points), where the oracle would take minutes: size-independent
+    properties of the sum.  (i) additivity over index ranges: MSM(all) = MSM(first part) + MSM(rest),
+    for an uneven split; (ii) homogeneity on an adversarial vector: all scalars equal to k gives
+    k * MSM(all ones) -- every window then has ONE bucket holding 2^20 entries (the heavy-bucket
+    path at its extreme); (iii) the three-in-flight queue returns the same bytes as one at a time."""
+    import numpy as np
+
+    gid, og = _grp(ps_api, co, name)
+    n = 1 << log2n
+    rng = np.random.default_rng(20)
+    raw_sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw_sc[:, 0] &= 0x3F  # < 2^254 < r: canonical without rejection
+    sc = ps_api.Poly.upload(ctx, raw_sc.tobytes())
+    seeds = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    seeds[:, 0] &= 0x3F
+    pts = ps_api.Points.from_scalars(ctx, gid, ps_api.Poly.upload(ctx, seeds.tobytes()))
+    whole = sc.BlindEval(pts)
+    cut = n // 3 + 1
+    parts = sc.slice(0, cut).BlindEval(pts.slice(0, cut)) + sc.slice(cut, n - cut).BlindEval(pts.slice(cut, n - cut))
+    assert ps_api.points_sum(gid, parts) == whole
+    # (iii) queue
+    for _ in range(3):
+        ps_api.msm_launch(ctx, pts, sc)
+    assert [ps_api.msm_finish(ctx, gid) for _ in range(3)] == [whole] * 3
+    # (ii) all-equal scalars
+    k = pr.SplitMix64(77).fr()
+    ones = ps_api.Poly.upload(ctx, (b"\x00" * 31 + b"\x01") * n)
+    total = ones.BlindEval(pts)
+    same = ps_api.Poly.upload(ctx, k.to_bytes(32, "big") * n)
+    got = same.BlindEval(pts)
+    want = ps_api.Poly.upload(ctx, [k]).BlindEval(ps_api.Points.upload(ctx, gid, total))
+    assert got == want
+    assert got == og.to_b(og.mul(k, og.from_b(total)))
