@@ -118,3 +118,26 @@ def test_sharded_phgr13_two_ranks_on_one_gpu(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert res.stdout.count("ok") == 2
+
+
+def test_sharded_phgr13_fold_on_the_host():
+    """ShardedPHGR13.fold adds the ranks' partial proofs element by element (host code only:
+    ps_points_sum); checked against the oracle's point additions, identity partials included."""
+    from oracle import coracle as co, pyref as pr
+    from playsnark_amd import api
+    from playsnark_amd.dist import ShardedPHGR13
+
+    rng = pr.SplitMix64(4711)
+    parts, want = [], {}
+    for g in range(3):
+        p = {}
+        for f in api.PHGR13Proof.FIELDS:
+            grp = co.G2 if f == "wss" else co.G1
+            pt = None if (g == 1 and f in ("hs", "wss")) else grp.mul(rng.fr())  # rank 1 had empty ranges there
+            p[f] = grp.to_b(pt)
+            want[f] = pt if f not in want else grp.add(want[f], pt)
+        parts.append(p)
+    folded = ShardedPHGR13.fold(parts)
+    for f in api.PHGR13Proof.FIELDS:
+        grp = co.G2 if f == "wss" else co.G1
+        assert getattr(folded, f) == grp.to_b(want[f]), f
