@@ -253,7 +253,9 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     if (p == 0) return (fuse.ld || fuse.st) ? hipErrorInvalidValue : hipSuccess;
     if (p > tb.log_tab) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
-    int npass = (p + NTT_MAX_K - 1) / NTT_MAX_K;
+    // a transform that fits one tile runs all its stages in one pass (contiguous in HBM: no stride to respect);
+    // longer ones are cut into passes of at most NTT_MAX_K stages so that a tile keeps >= 8 contiguous columns
+    int npass = p <= NTT_TILE_LOG ? 1 : (p + NTT_MAX_K - 1) / NTT_MAX_K;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
     int done = 0, unscaled = 0;  // unscaled: inverse stages whose factor 2 per stage has not been divided out yet
     for (int ps_i = 0; ps_i < npass; ps_i++) {
