@@ -13,7 +13,7 @@
 //     representation (field.cuh) values grow by ~r per stage and need no reduction at all; the
 //     inverse doubles per stage along the all-sums path; the factor is divided out by the last pass
 //     (and by an earlier one only if it would pass 2^16).
-// A transform of 2^p points is cut into ceil(p/8) passes; each pass stages a tile of 2^k rows x
+// A transform of 2^p points is cut into ceil(p/10) passes; each pass stages a tile of 2^k rows x
 // COLS columns (2048 Fr = 80 KB) in LDS, runs k butterfly stages there, and touches HBM exactly
 // once for reading and once for writing.  Batched transforms (many blocks of 2^p points back to
 // back) use the same kernel: butterflies never cross a 2^p boundary.
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
     tw[i] = acc;
 }
 
-constexpr int NTT_MAX_K = 8;        // butterfly stages per pass
+constexpr int NTT_MAX_K = 10;       // butterfly stages per pass (a tile then keeps >= 2 contiguous columns = 80 B runs)
 constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
 
 // One pass over transforms of 2^p points: k stages with half-distances D*2^m, m = k-1..0 for the
@@ -254,7 +254,8 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     if (p > tb.log_tab) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
     // a transform that fits one tile runs all its stages in one pass (contiguous in HBM: no stride to respect);
-    // longer ones are cut into passes of at most NTT_MAX_K stages so that a tile keeps >= 8 contiguous columns
+    // longer ones are cut into passes of at most NTT_MAX_K stages: fewer, longer passes win as long as a
+    // tile keeps a couple of contiguous columns (measured at 2^20: 8 stages 12.25 ms, 9: 11.9, 10: 11.9)
     int npass = p <= NTT_TILE_LOG ? 1 : (p + NTT_MAX_K - 1) / NTT_MAX_K;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
     int done = 0, unscaled = 0;  // unscaled: inverse stages whose factor 2 per stage has not been divided out yet
