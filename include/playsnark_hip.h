@@ -169,6 +169,14 @@ int ps_groth16_prove(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, cons
                      const uint8_t r_be32[32], const uint8_t s_be32[32], uint8_t A[96], uint8_t B[192],
                      uint8_t C[96]);
 
+/* One rank's share of Groth16Prove when the sums are sharded over `world` GPUs (one process each): rank g
+ * takes its index range of every CRS array, rank 0 also the fixed points; A_part / B_part / C_part of all
+ * ranks add up (ps_points_sum, after an all_gather) to the A, B, C of ps_groth16_prove.  Every rank
+ * computes the quotient itself. */
+int ps_groth16_prove_shard(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, const ps_scalars* sol,
+                           const uint8_t r_be32[32], const uint8_t s_be32[32], int rank, int world, uint8_t A_part[96],
+                           uint8_t B_part[192], uint8_t C_part[96]);
+
 typedef struct { /* PHGR13EvalKey (pinochio.go:37-62); ws is G2, every other array is G1 */
     const ps_points *vs, *ws, *ys, *vas, *was, *yas, *gsi, *vbs, *wbs, *ybs;
 } ps_phgr13_ek;

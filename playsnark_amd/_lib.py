@@ -28,7 +28,7 @@ SYMBOLS = [
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
-    "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
+    "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_groth16_prove_shard", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
 ]
 
 
@@ -149,6 +149,8 @@ def _load():
     lib.ps_poly_mul.argtypes = [vp, vp, vp, pp]
     lib.ps_groth16_prove.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_char_p, C.c_char_p]
+    lib.ps_groth16_prove_shard.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, i, i, C.c_char_p,
+                                           C.c_char_p, C.c_char_p]
     lib.ps_phgr13_prove.argtypes = [vp, C.POINTER(Phgr13Ek), vp, vp, C.POINTER(Phgr13Proof)]
     lib.ps_groth16_setup.argtypes = [vp, vp, C.POINTER(Groth16Toxic), C.POINTER(Groth16Crs)]
     lib.ps_phgr13_setup.argtypes = [vp, vp, C.POINTER(Phgr13Toxic), C.POINTER(Phgr13Crs)]

@@ -98,6 +98,12 @@ whole = api.PHGR13Prove(ek, q, sol_dev)
 got = ShardedPHGR13(ctx, dist, world, rank).prove(ek, q, sol_dev)
 for f in api.PHGR13Proof.FIELDS:
     assert getattr(got, f) == getattr(whole, f), (rank, f)
+from playsnark_amd.dist import ShardedGroth16
+tr, _ = api.NewGroth16TrustedSetup(q, *[rng.fr() for _ in range(5)])
+r, s = rng.fr(), rng.fr()
+g_whole = api.Groth16Prove(tr, q, sol_dev, r, s)
+g_got = ShardedGroth16(ctx, dist, world, rank).prove(tr, q, sol_dev, r, s)
+assert (g_got.A, g_got.B, g_got.C) == (g_whole.A, g_whole.B, g_whole.C), rank
 dist.destroy_process_group()
 print("rank", rank, "ok")
 """
@@ -107,9 +113,9 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_sharded_phgr13_two_ranks_on_one_gpu(tmp_path):
-    """Two processes (gloo for the exchange, both on GPU 0): each proves its index ranges, the
-    all_gather + fold gives every rank the unsharded proof."""
+def test_sharded_provers_two_ranks_on_one_gpu(tmp_path):
+    """Two processes (gloo for the exchange, both on GPU 0): each proves its index ranges of a PHGR13 and
+    of a Groth16 proof, the all_gather + fold gives every rank the unsharded proofs."""
     script = tmp_path / "worker.py"
     script.write_text(PHGR13_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")

@@ -335,3 +335,26 @@ def test_sharded_phgr13_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
         folded = sh.fold([sh.partials(ek, q, sol_dev, rank=g) for g in range(world)])
         for f in ps_api.PHGR13Proof.FIELDS:
             assert getattr(folded, f) == getattr(whole, f), f
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_groth16_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
+    """The shares that `world` ranks compute with ps_groth16_prove_shard (index ranges of Xi, Xi2, NioLP,
+    XiT; fixed points on rank 0), folded, are the unsharded proof byte for byte -- for both positions of
+    the reference's `diff` split and with more ranks than some arrays have elements."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedGroth16
+
+    rng = pr.SplitMix64(SEED + 808 + world)
+    c, sol = rs.synthetic_circuit(45)
+    for cc in (c, rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)):
+        q = _upload_circuit(ps_api, ctx, cc)
+        tr, _ = ps_api.NewGroth16TrustedSetup(q, *[rng.fr() for _ in range(5)])
+        sol_dev = ps_api.Poly.upload(ctx, sol)
+        r, s = rng.fr(), rng.fr()
+        whole = ps_api.Groth16Prove(tr, q, sol_dev, r, s)
+        sh = ShardedGroth16(ctx, None, world, 0)
+        folded = sh.fold([sh.partials(tr, q, sol_dev, r, s, rank=g) for g in range(world)], r, s)
+        assert (folded.A, folded.B, folded.C) == (whole.A, whole.B, whole.C)
+    with pytest.raises(ps_api.PlaysnarkError):
+        ShardedGroth16(ctx, None, 2, 0).partials(tr, q, sol_dev, r, s, rank=2)
