@@ -158,6 +158,16 @@ inline Groth16Proof Groth16Prove(Context& c, const ps_groth16_pk& tr, const QAP&
     return p;
 }
 
+// One rank's share of Groth16Prove when the sums are split over `world` GPUs; the ranks' A, B, C add up
+// (ps_points_sum after an all_gather) to the proof
+inline Groth16Proof Groth16ProveShard(Context& c, const ps_groth16_pk& tr, const QAP& q, const Poly& sol, const Scalar& r,
+                                      const Scalar& s, int rank, int world) {
+    Groth16Proof p{r, s, {}, {}, {}};
+    check(ps_groth16_prove_shard(c.get(), &tr, q.get(), sol.get(), r.data(), s.data(), rank, world, p.A.data(), p.B.data(),
+                                 p.C.data()));
+    return p;
+}
+
 // func PHGR13Prove(ek PHGR13EvalKey, qap QAP, solution Vector) PHGR13Proof
 inline ps_phgr13_proof PHGR13Prove(Context& c, const ps_phgr13_ek& ek, const QAP& qap, const Poly& solution) {
     ps_phgr13_proof out;
