@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 SEED = 0x706C6179736E61726B & 0xFFFFFFFFFFFFFFFF  # "playsnark"
 MAD_PEAK_PER_S = 2.82e13  # measured v_mad_u64_u32 lane-ops/s, profiles/r01_microbench_valu.txt
-MADS_PER_MIXED_ADD = {"g1": 3542, "g2": 2 * 5488}  # 8M+2S: 6*392 + 588 + 2*301; G2: (8*588 + 2*392) per lane of a pair
+MADS_PER_MIXED_ADD = {"g1": 3542, "g2": 2 * 5292}  # 8M+2S: 6*392 + 588 + 2*301; G2 per lane of a pair: 6*588 + 980 + 2*392
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SCALAR_MUL = 96 + 32                    # one affine G1 point + one scalar
 
