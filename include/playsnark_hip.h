@@ -55,8 +55,14 @@ void* ps_ctx_stream(ps_ctx* ctx);
 
 /* ---- CRS / evaluation-key arrays: the []G1 / []G2 slices of Groth16Setup
  *      (groth16.go:30-61: Xi, Xi2, NioLP, XiT) and PHGR13EvalKey (pinochio.go:37-62) ---- */
+/* Encodings are validated (canonical field elements, curve equation, identity = 0x40 then zeros / 0xC0 then
+ * zeros): PS_ERR_ENCODING otherwise.  Membership in the order-r subgroup is NOT tested here (it costs a
+ * scalar multiplication per point); arrays that come from an untrusted source go through
+ * ps_points_check_subgroup, as kyber's UnmarshalBinary would have rejected such points [upstream]. */
 int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts, size_t n, int fmt,
                      ps_points** out);
+/* *ok = 1 iff [r]P = O for every point of the array (GPU, ~400 group operations per point). */
+int ps_points_check_subgroup(ps_ctx* ctx, const ps_points* p, int* ok);
 /* out[i] = scalars[i] * G (fixed base).  GeneratePowersCommit (algebra.go:371-384) and the
  * commit loops of fullLinearPoly (groth16.go:254-264) / generateEvalCommit (pinochio.go:381-388)
  * reduce to this once the exponents are known. */
@@ -88,7 +94,11 @@ void ps_scalars_free(ps_scalars* s);
 /* ---- MSM: Poly.BlindEval (algebra.go:348-359), sumBlind (groth16.go:134-141), the NioLP loop
  *      (groth16.go:173-179), computeSolCommit (pinochio.go:222-229) ----
  * out = sum_i scalars[i] * points[i].  len(scalars) != len(points) returns PS_ERR_LENGTH, the
- * reference's panic at algebra.go:350-352.  `out` is 96 B (G1) or 192 B (G2), affine. */
+ * reference's panic at algebra.go:350-352.  `out` is 96 B (G1) or 192 B (G2), affine.
+ * Size limit: windows x length < 2^32 digits (32-bit sort offsets): 2^28 full-width scalars per call,
+ * PS_ERR_ARG beyond (split with ps_points_slice / ps_scalars_slice and add the parts with ps_points_sum).
+ * Ordering: arrays returned by the asynchronous producers (ps_points_from_scalars,
+ * ps_scalars_from_device_be32) may be passed on at once -- every sum waits for its own inputs. */
 int ps_msm(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars, uint8_t* out);
 /* Host-buffer convenience forms (upload + ps_msm). */
 int ps_msm_be32(ps_ctx* ctx, const ps_points* points, const uint8_t* scalars_be32, size_t n, uint8_t* out);
@@ -219,7 +229,10 @@ typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */
     uint8_t beta2[192], gamma[192], delta2[192]; /* G2 */
     const ps_points* io_lp;                   /* IoLP, nbVars - nbIO G1 points (`diff` convention) */
 } ps_groth16_vk;
-/* Groth16Verify (groth16.go:214-233); io = sol[:diff] as in groth16_test.go:29.  *ok = 1/0. */
+/* Groth16Verify (groth16.go:214-233); io = sol[:diff] as in groth16_test.go:29.  *ok = 1/0.
+ * Both verifiers and ps_pairing_equal treat every point they are given as untrusted: canonical encoding, on
+ * the curve and in the order-r subgroup ([r]P = O), PS_ERR_ENCODING otherwise -- the checks the reference gets
+ * from kyber's UnmarshalBinary before its Verify functions ever see a point [upstream]. */
 int ps_groth16_verify(ps_ctx* ctx, const ps_groth16_vk* vk, const ps_scalars* io, const uint8_t A[96], const uint8_t B[192],
                       const uint8_t C[96], int* ok);
 typedef struct { /* PHGR13VerifKey (pinochio.go:64-91); the *_io arrays are vk.vs[:diff], vk.ws[:diff], vk.ys[:diff] */

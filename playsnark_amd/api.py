@@ -182,6 +182,12 @@ class Points:
         _check(lib.ps_points_slice(self._h, first, n, C.byref(h)))
         return Points(self.ctx, h, owner=self)
 
+    def in_subgroup(self) -> bool:
+        """[r]P = O for every point (what kyber's UnmarshalBinary enforces on the Go side [upstream])."""
+        ok = C.c_int(0)
+        _check(lib.ps_points_check_subgroup(self.ctx._h, self._h, C.byref(ok)))
+        return bool(ok.value)
+
     def free(self):
         if self._h:
             lib.ps_points_free(self._h)
@@ -348,6 +354,33 @@ class QAP:
         self._h = h
 
     @classmethod
+    def from_csr(cls, ctx: Context, nbVars: int, nbIO: int, left, right, out) -> "QAP":
+        """The three matrices as (row_ptr, col, val) triples of array-likes exposing the buffer protocol
+        (numpy uint32 / uint32 / int64): no per-row Python lists, for circuits of millions of gates."""
+        self = cls.__new__(cls)
+        self.ctx, self.nbVars, self.nbIO = ctx, nbVars, nbIO
+        self.nbGates = len(left[0]) - 1
+        structs, keep = [], []
+        for row_ptr, col, val in (left, right, out):
+            arrs = []
+            for a, ct in ((row_ptr, C.c_uint32), (col, C.c_uint32), (val, C.c_int64)):
+                mv = memoryview(a).cast("B")
+                if mv.nbytes % C.sizeof(ct):
+                    raise ValueError("CSR array of the wrong element type")
+                buf = (ct * max(mv.nbytes // C.sizeof(ct), 1))()
+                C.memmove(buf, mv.tobytes(), mv.nbytes)
+                arrs.append(buf)
+            if len(arrs[0]) != self.nbGates + 1:
+                raise LengthMismatch("row_ptr arrays of different lengths")
+            keep.append(arrs)
+            structs.append(_lib.Csr(*[C.cast(a, C.c_void_p) for a in arrs]))
+        h = C.c_void_p()
+        _check(lib.ps_qap_create(ctx._h, self.nbGates, nbVars, nbIO, C.byref(structs[0]), C.byref(structs[1]),
+                                 C.byref(structs[2]), C.byref(h)))
+        self._h = h
+        return self
+
+    @classmethod
     def from_dense(cls, ctx: Context, nbVars: int, nbIO: int, left, right, out) -> "QAP":
         """ToQAP(circuit R1CS) (qap.go:35) from the dense matrices of r1cs.go:99-101."""
         return cls(ctx, nbVars, nbIO, dense_to_rows(left), dense_to_rows(right), dense_to_rows(out))
@@ -356,6 +389,13 @@ class QAP:
         """(left, right, out Poly) of qap.go:164-175 plus h in one pass."""
         hs = [C.c_void_p() for _ in range(4)]
         _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, *[C.byref(h) for h in hs]))
+        return tuple(Poly(self.ctx, h) for h in hs)
+
+    def computeAB(self, sol: Poly):
+        """(left, right, h): the Groth16 route -- A and B as coefficient vectors, h = floor(A*B / z); C is never
+        interpolated (what Groth16Prove needs, groth16.go:146-185)."""
+        hs = [C.c_void_p() for _ in range(3)]
+        _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, C.byref(hs[0]), C.byref(hs[1]), None, C.byref(hs[2])))
         return tuple(Poly(self.ctx, h) for h in hs)
 
     def Quotient(self, sol: Poly) -> Poly:

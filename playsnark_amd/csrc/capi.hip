@@ -122,12 +122,27 @@ struct ps_ctx {
 struct Storage {  // shared device allocation behind slices
     void* p = nullptr;
     int refs = 1;
+    // Recorded by a producer that returns before its kernel has run (ps_points_from_scalars,
+    // ps_scalars_from_device_be32); every stream that consumes the array waits for it first.
+    hipEvent_t ready = nullptr;
 };
 static void storage_unref(Storage* s) {
     if (s && --s->refs == 0) {
+        if (s->ready) (void)hipEventDestroy(s->ready);
         if (s->p) (void)hipFree(s->p);
         delete s;
     }
+}
+static int storage_mark_ready(Storage* s, hipStream_t producer) {
+    if (!s->ready) {
+        hipError_t e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
+        if (e != hipSuccess) { s->ready = nullptr; return PS_ERR_HIP; }
+    }
+    return hipEventRecord(s->ready, producer) == hipSuccess ? PS_OK : PS_ERR_HIP;
+}
+static int storage_wait_ready(const Storage* s, hipStream_t consumer) {
+    if (!s->ready) return PS_OK;
+    return hipStreamWaitEvent(consumer, s->ready, 0) == hipSuccess ? PS_OK : PS_ERR_HIP;
 }
 
 static unsigned long long g_points_uid = 0;
@@ -253,6 +268,7 @@ extern "C" int ps_scalars_from_device_be32(ps_ctx* c, const void* d_be32, size_t
     if (n) hipLaunchKernelGGL(k_scalars_from_be32, dim3(nblocks(n)), dim3(256), 0, c->stream, (const uint8_t*)d_be32,
                               (u32)n, (u32*)(*out)->st->p);
     HIP_TRY(hipGetLastError());
+    if (storage_mark_ready((*out)->st, c->stream)) return fail(PS_ERR_HIP, "ps_scalars_from_device_be32: event record failed");
     return PS_OK;
 }
 
@@ -296,6 +312,7 @@ extern "C" int ps_scalars_download(ps_ctx* c, const ps_scalars* s, size_t first,
     if (first + n > s->n) return fail(PS_ERR_LENGTH, "ps_scalars_download: range out of bounds");
     if (!n) return PS_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (storage_wait_ready(s->st, c->stream)) return fail(PS_ERR_HIP, "ps_scalars_download: event wait failed");
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = c->staging.ensure(32 * n);
     if (rc) return rc;
@@ -405,7 +422,9 @@ extern "C" int ps_points_from_scalars(ps_ctx* c, int group, const ps_scalars* k,
     HIP_TRY(hipSetDevice(c->device));
     int rc = points_alloc(c, group, k->n, out);
     if (rc) return rc;
+    if (storage_wait_ready(k->st, c->stream)) return fail(PS_ERR_HIP, "ps_points_from_scalars: event wait failed");
     rc = group == PS_G1 ? fixed_base<Fp>(c, 0, k, *out) : fixed_base<Fp2>(c, 1, k, *out);
+    if (!rc && storage_mark_ready((*out)->st, c->stream)) rc = fail(PS_ERR_HIP, "ps_points_from_scalars: event record failed");
     if (rc) {
         ps_points_free(*out);
         *out = nullptr;
@@ -418,6 +437,7 @@ extern "C" int ps_points_download(ps_ctx* c, const ps_points* p, size_t first, s
     if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_download: range out of bounds");
     if (!n) return PS_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (storage_wait_ready(p->st, c->stream)) return fail(PS_ERR_HIP, "ps_points_download: event wait failed");
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t wb = wire_bytes(p->group);
     int rc = c->staging.ensure(wb * n);
@@ -441,6 +461,7 @@ extern "C" int ps_points_download_fmt(ps_ctx* c, const ps_points* p, size_t firs
     if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_download_fmt: range out of bounds");
     if (!n) return PS_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (storage_wait_ready(p->st, c->stream)) return fail(PS_ERR_HIP, "ps_points_download_fmt: event wait failed");
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t wb = wire_bytes(p->group) / 2;
     int rc = c->staging.ensure(wb * n);
@@ -471,6 +492,30 @@ extern "C" void ps_points_free(ps_points* p) {
     (void)hipSetDevice(p->device);
     storage_unref(p->st);
     delete p;
+}
+
+// Every point of the array in the order-r subgroup?  ([r]P on the device: ~400 group operations per point;
+// an opt-in check for arrays that arrive from outside -- ps_points_upload itself only tests the curve equation.)
+extern "C" int ps_points_check_subgroup(ps_ctx* c, const ps_points* p, int* ok) {
+    if (!c || !p || !ok) return fail(PS_ERR_ARG, "ps_points_check_subgroup: NULL argument");
+    *ok = 0;
+    HIP_TRY(hipSetDevice(c->device));
+    if (storage_wait_ready(p->st, c->stream)) return fail(PS_ERR_HIP, "ps_points_check_subgroup: event wait failed");
+    HIP_TRY(hipMemsetAsync(c->d_flag, 0, 4, c->stream));
+    if (p->n) {
+        if (p->group == PS_G1)
+            hipLaunchKernelGGL(k_points_subgroup<Fp>, dim3(nblocks(p->n)), dim3(256), 0, c->stream, (const Affine<Fp>*)points_ptr(p),
+                               (u32)p->n, c->d_flag);
+        else
+            hipLaunchKernelGGL(k_points_subgroup<Fp2>, dim3(nblocks(p->n)), dim3(256), 0, c->stream, (const Affine<Fp2>*)points_ptr(p),
+                               (u32)p->n, c->d_flag);
+    }
+    HIP_TRY(hipGetLastError());
+    u32 nbad = 0;
+    HIP_TRY(hipMemcpyAsync(&nbad, c->d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *ok = nbad == 0;
+    return PS_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -504,14 +549,20 @@ static void write_affine(uint8_t* out, const Xyzz<Fp2>& acc) {
     fp_to_be48_host(out + 96, y.c1);
     fp_to_be48_host(out + 144, y.c0);
 }
+static bool is_identity_encoding(const uint8_t* p, size_t wb) {  // 0x40 followed by zeros, nothing else
+    if (p[0] != 0x40) return false;
+    for (size_t i = 1; i < wb; i++)
+        if (p[i]) return false;
+    return true;
+}
 static bool read_affine(Affine<Fp>& a, const uint8_t* p) {
-    if (p[0] & 0x40) { a.x = fp_zero(); a.y = fp_zero(); return true; }
+    if (p[0] & 0x40) { a.x = fp_zero(); a.y = fp_zero(); return is_identity_encoding(p, 96); }
     if (p[0] & 0xE0) return false;
     if (!fp_from_be48_host(a.x, p) || !fp_from_be48_host(a.y, p + 48)) return false;
     return affine_on_curve<Fp>(a);
 }
 static bool read_affine(Affine<Fp2>& a, const uint8_t* p) {
-    if (p[0] & 0x40) { a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0); return true; }
+    if (p[0] & 0x40) { a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0); return is_identity_encoding(p, 192); }
     if (p[0] & 0xE0) return false;
     if (!fp_from_be48_host(a.x.c1, p) || !fp_from_be48_host(a.x.c0, p + 48) || !fp_from_be48_host(a.y.c1, p + 96) ||
         !fp_from_be48_host(a.y.c0, p + 144))
@@ -580,6 +631,7 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
     hipStream_t st = c->stream;
     if (c->tail_used) HIP_TRY(hipStreamWaitEvent(st, c->ev_tail_done, 0));  // the last tail still reads offs
+    if (storage_wait_ready(sc->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced scalars
     int evi = 0;
     PS_STAGE_MARK();  // 0: start
     HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
@@ -642,6 +694,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
+    if (storage_wait_ready(pts->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced points
     HIP_TRY(hipMemsetAsync(wc->heavy.p, 0, 4, st));
     HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
@@ -687,6 +740,18 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     return PS_OK;
 }
 #undef PS_STAGE_MARK
+
+// Plan of a sum on context `c`.  Entry offsets, ranks and totals are 32-bit (k_scan_*, k_scatter, the sorted
+// list): a sum whose W * n digits would not fit is refused rather than wrapped (W = 16 windows: n < 2^28).
+static int msm_plan_checked(const ps_ctx* c, size_t n, int max_bits, MsmPlan* out) {
+    MsmPlan pl = msm_plan(n, max_bits, c->forced_c);
+    if (c->forced_slice) pl.M = c->forced_slice;
+    if ((u64)pl.W * (u64)n >= (1ull << 32))
+        return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +
+                                    " digits do not fit the 32-bit sort offsets (split the sum, e.g. ps_points_slice)");
+    *out = pl;
+    return PS_OK;
+}
 
 static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl, hipEvent_t wait_acc,
                           hipEvent_t acc_done) {
@@ -784,8 +849,8 @@ extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, co
         return PS_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
-    MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
-    if (c->forced_slice) pl.M = c->forced_slice;
+    MsmPlan pl;
+    if ((rc = msm_plan_checked(c, sc->n, sc->max_bits, &pl))) return rc;
     if (k > 1 && !c->aux && (rc = ps_ctx_create(c->device, &c->aux))) return rc;
     if (c->aux && c->aux->pending) return fail(PS_ERR_ARG, "ps_msm_multi: the auxiliary context is busy");
     if ((rc = msm_multi_launch(c, c, k > 1 ? c->aux : c, pts, k, sc, pl))) return rc;
@@ -821,15 +886,19 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
     }
     // Inputs enqueued on the context stream before the FIRST launch of a burst are visible to the worker
     // streams: the fork event is recorded while the queue is empty, ahead of that launch's own kernels
-    // (recording it later would order a worker's sort behind the running accumulation).
+    // (recording it later would order a worker's sort behind the running accumulation).  Arrays that a
+    // producer left in flight on some stream (ps_points_from_scalars, ps_scalars_from_device_be32) carry
+    // their own ready event, which msm_sort / msm_points_t make the worker stream wait for -- so inputs
+    // produced between two launches of a burst are ordered as well.
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     if (c->q_len == 0) HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     ps_ctx::PendingMsm& e = c->q[(c->q_head + c->q_len) % PS_MSM_QUEUE];
     if (sc->n == 0) {
         e = {pts->group, MsmPlan{}, wc};
     } else {
-        MsmPlan pl = msm_plan(sc->n, sc->max_bits, c->forced_c);
-        if (c->forced_slice) pl.M = c->forced_slice;
+        MsmPlan pl;
+        int rc0 = msm_plan_checked(c, sc->n, sc->max_bits, &pl);
+        if (rc0) return rc0;
         if (wc != c) HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
         // chain the accumulations: this one starts when the previously launched one is done
         hipEvent_t wait = (c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;

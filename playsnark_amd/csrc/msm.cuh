@@ -697,8 +697,11 @@ __global__ void __launch_bounds__(256) k_points_from_bytes_g1(const uint8_t* __r
     if (i >= n) return;
     const uint8_t* p = in + 96 * (size_t)i;
     Affine<Fp> a;
-    if (p[0] & 0x40) {
+    if (p[0] & 0x40) {  // the identity is 0x40 followed by zeros, nothing else
         a.x = fp_zero(); a.y = fp_zero();
+        bool zero = p[0] == 0x40;
+        for (int j = 1; j < 96; j++) zero = zero && p[j] == 0;
+        if (!zero) atomicAdd(nbad, 1u);
     } else {
         bool ok = (p[0] & 0xE0) == 0;
         a.x = fp_from_be48(p, ok);
@@ -716,6 +719,9 @@ __global__ void __launch_bounds__(256) k_points_from_bytes_g2(const uint8_t* __r
     Affine<Fp2> a;
     if (p[0] & 0x40) {
         a.x = f_zero((const Fp2*)0); a.y = f_zero((const Fp2*)0);
+        bool zero = p[0] == 0x40;
+        for (int j = 1; j < 192; j++) zero = zero && p[j] == 0;
+        if (!zero) atomicAdd(nbad, 1u);
     } else {
         bool ok = (p[0] & 0xE0) == 0;
         a.x.c1 = fp_from_be48(p, ok);
@@ -829,6 +835,23 @@ __global__ void __launch_bounds__(256) k_points_decompress(const uint8_t* __rest
         a.x = f_zero((const F*)0); a.y = f_zero((const F*)0);
     }
     out[i] = a;
+}
+
+// [r]P == O ?  On-curve points of E(Fp) / E'(Fp2) outside the order-r subgroup exist (cofactors
+// 0x396c8c005555e1568c00aaab0000aaab and a 509-bit one); kyber's UnmarshalBinary rejects them [upstream],
+// and the signed-digit folding (r - |v|)P = -(|v|P) and the Miller loop both assume order r.
+template <class F>
+PS_HD inline bool affine_in_subgroup(const Affine<F>& a) {
+    if (fp_all_zero(a.x) && fp_all_zero(a.y)) return true;
+    u32 r[8];
+    for (int i = 0; i < 8; i++) r[i] = FrParams::mod(i);
+    return xyzz_is_identity(xyzz_mul_scalar<F>(xyzz_from_affine<F>(a.x, a.y), r));
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_points_subgroup(const Affine<F>* __restrict__ in, u32 n, u32* __restrict__ nbad) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!affine_in_subgroup<F>(in[i])) atomicAdd(nbad, 1u);
 }
 
 PS_INL Affine<Fp> generator(const Fp*) {

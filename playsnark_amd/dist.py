@@ -84,11 +84,20 @@ class ShardedPHGR13:
         """This rank's share of every proof element (affine bytes; the identity for an empty range)."""
         rank = self.rank if rank is None else rank
         ctx = self.ctx
+        # The index-range split needs every array to match its scalars, as BlindEval does (algebra.go:350-352):
+        # a longer array would be silently truncated by the slices below, where the unsharded prover panics.
+        diff = qap.nbVars - qap.nbIO
+        nn = len(ek.vs)
+        for f in ("vs", "ws", "ys", "vas", "was", "yas", "vbs", "wbs", "ybs"):
+            if len(getattr(ek, f)) != nn:
+                raise api.LengthMismatch(f"evaluation-key arrays of different lengths: vs {nn}, {f} {len(getattr(ek, f))}")
+        if diff + nn > len(solution):
+            raise api.LengthMismatch("evaluation-key array longer than the non-IO part of the solution")
+        if len(ek.gsi) != qap.nbGates - 1:
+            raise api.LengthMismatch(f"mismatch of length between poly {qap.nbGates - 1} and blinded eval points {len(ek.gsi)}")
         h = qap.Quotient(solution)  # raises Apocalypse exactly as the unsharded prover
         first, cnt = shard_range(len(h), rank, self.world)
         out = {"hs": h.slice(first, cnt).BlindEval(ek.gsi.slice(first, cnt))}
-        diff = qap.nbVars - qap.nbIO
-        nn = len(ek.vs)
         first, cnt = shard_range(nn, rank, self.world)
         names = ("vs", "ws", "ys", "vas", "was", "yas", "vbs", "wbs", "ybs")
         arrays = [getattr(ek, f).slice(first, cnt) for f in names]

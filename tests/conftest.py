@@ -41,3 +41,28 @@ def ctx(ps_api):
     c = ps_api.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def off_subgroup(pr):
+    """(G1 point, G2 point) on the curve E(Fp) / the twist E'(Fp2) but NOT in the order-r subgroup: the cofactors
+    are huge, so the first x with a square right-hand side almost surely gives one.  [r]P is computed as
+    (r-1)P + P because the oracle's Mul reduces its scalar mod r, like kyber's."""
+    times_r = lambda grp, pt: grp.add(grp.mul(pr.R - 1, pt), pt)
+    x = 4
+    while True:
+        y = pr.fp_sqrt((x * x * x + 4) % pr.P)
+        if y is not None and times_r(pr.G1, (x, y)) is not None:
+            g1 = (x, y)
+            break
+        x += 1
+    x = 1
+    while True:
+        X = (x, 1)
+        y = pr.f2_sqrt(pr.f2_add(pr.f2_mul(pr.f2_sqr(X), X), (4, 4)))
+        if y is not None and times_r(pr.G2, (X, y)) is not None:
+            g2 = (X, y)
+            break
+        x += 1
+    assert pr.G1.on_curve(g1) and pr.G2.on_curve(g2)
+    return g1, g2

@@ -103,3 +103,56 @@ def test_point_convert_matches_zcash_encoding(co, pr):
 
 def _neg(pr, y):
     return (-y) % pr.P if isinstance(y, int) else ((-y[0]) % pr.P, (-y[1]) % pr.P)
+
+
+def _fixture_file(tmp_path):
+    """tests/golden/groth16_toy.json (+ gamma from its toxic waste, h0 from toy_qap.json) as `name hex` lines for the C programs."""
+    import json
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "groth16_toy.json")))
+    toy = json.load(open(os.path.join(ROOT, "tests", "golden", "toy_qap.json")))
+    lines = [f"{k} {v}" for k, v in g.items() if isinstance(v, str)]
+    lines.append("gamma " + g["toxic"]["gamma"])
+    lines.append("h0 " + toy["h"][0])
+    path = tmp_path / "groth16_toy.txt"
+    path.write_text("\n".join(lines) + "\n")
+    return str(path)
+
+
+def _build_smoke(tmp_path, lang):
+    pkg = os.path.join(ROOT, "playsnark_amd")
+    link = ["-L" + pkg, "-lplaysnark_hip", "-Wl,-rpath," + pkg]
+    if lang == "c":  # -pedantic C99: the header is a C header, not a C++ one in disguise
+        exe = str(tmp_path / "abi_smoke")
+        cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+               os.path.join(ROOT, "tests", "abi_smoke.c"), "-o", exe] + link
+    else:  # compiles playsnark_amd/host/playsnark.hpp, the C++ mirror of the reference's surface
+        exe = str(tmp_path / "abi_smoke_cpp")
+        cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + ROOT, os.path.join(ROOT, "tests", "abi_smoke_cpp.cpp"), "-o", exe] + link
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return exe
+
+
+@pytest.mark.parametrize("lang", ["c", "cpp"])
+def test_foreign_callers_compile_link_and_fail_loudly_without_a_gpu(tmp_path, lang):
+    """A plain-C caller (what cgo generates) and a C++ caller of host/playsnark.hpp build against the header and the
+    shared library alone; without a device they report PS_ERR_NO_DEVICE (exit 77) -- no CPU fallback."""
+    from playsnark_amd import api
+
+    exe = _build_smoke(tmp_path, lang)
+    res = subprocess.run([exe, _fixture_file(tmp_path)], capture_output=True, text=True, timeout=300)
+    if api.device_count() == 0:
+        assert res.returncode == 77, res.stdout + res.stderr
+    else:
+        assert res.returncode == 0, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lang", ["c", "cpp"])
+def test_foreign_callers_prove_the_toy_circuit(tmp_path, lang):
+    """tests/abi_smoke.c / abi_smoke_cpp.cpp on the GPU: the toy Groth16 proof equals tests/golden/groth16_toy.json."""
+    exe = _build_smoke(tmp_path, lang)
+    res = subprocess.run([exe, _fixture_file(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ok" in res.stdout

@@ -1,0 +1,94 @@
+"""bench.py's host logic: the synthetic R1CS it proves in `extras` is the oracle's synthetic circuit, and
+`python3 bench.py --gpus N` starts N ranks by itself (a driver-run SCALE record must never be a silent one-GPU
+number).  CPU tests; the two-rank rehearsal on a real GPU is gpu-marked."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench
+
+
+def test_synthetic_r1cs_is_the_oracles_synthetic_circuit():
+    from oracle import restate as rs
+
+    bench = _bench()
+    for n in (4, 8, 64, 1024):
+        nvars, L, Rm, O, sol = bench.synthetic_r1cs(n)
+        c, want_sol = rs.synthetic_circuit(n)
+        assert nvars == c.nbVars and sol == want_sol
+        for (ptr, col, val), rows in ((L, c.left), (Rm, c.right), (O, c.out)):
+            got = [sorted((int(col[e]), int(val[e])) for e in range(ptr[g], ptr[g + 1])) for g in range(n)]
+            assert got == [sorted(r) for r in rows]
+
+
+def test_quotient_work_counts_match_design():
+    bench = _bench()
+    nbytes, bfly = bench.quotient_work(1 << 20)
+    assert nbytes == 74 * (1 << 20) * 80            # 74 x 2^20 element-transforms, 2 x 40 B each
+    assert bfly == 567 * (1 << 20)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch, capsys):
+    """No WORLD_SIZE and --gpus 4: one child process of torch.distributed.run with --nproc-per-node=4, the
+    caller's flags passed through, rank 0's JSON line relayed, other output sent to stderr."""
+    bench = _bench()
+    seen = {}
+
+    class Done:
+        returncode = 0
+        stdout = 'noise from a rank\n{"metric": "G1 scalar-muls/s", "n_gpus": 4}\n'
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--total-log2n", "24"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--total-log2n", "24"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert json.loads(out.out.strip())["n_gpus"] == 4 and "noise from a rank" in out.err
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus(monkeypatch):
+    bench = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2 but --gpus 8" in str(e.value.code)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python3 bench.py --gpus 2` as the driver types it (no torchrun around it): two ranks (gloo for the exchange,
+    both on GPU 0), weak and strong scaling lines."""
+    env = dict(os.environ, PS_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1"]
+    res = subprocess.run(base + ["--log2n", "14"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["devices"] == [0, 0]
+    assert line["config"]["points_per_gpu"] == 1 << 14 and line["value"] > 0 and "cpu_baseline" not in line
+    res = subprocess.run(base + ["--total-log2n", "15"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["points_per_gpu"] == 1 << 14
+    assert "2^15 points in total" in line["config"]["workload"]

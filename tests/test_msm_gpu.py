@@ -406,3 +406,159 @@ def test_full_size_properties_2pow20(ps_api, ctx, co, pr, name, log2n):
     want = ps_api.Poly.upload(ctx, [k]).BlindEval(ps_api.Points.upload(ctx, gid, total))
     assert got == want
     assert got == og.to_b(og.mul(k, og.from_b(total)))
+
+
+def _uniform_be32(n, seed):
+    """n scalars < 2^254 < r (canonical without rejection) as big-endian rows."""
+    import numpy as np
+
+    rows = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    rows[:, 0] &= 0x3F
+    return rows
+
+
+def _witness_i64(n, seed):
+    """SURVEY 8d regime ii: 40-bit values, a tenth zeros, a tenth ones, a quarter negative."""
+    import numpy as np
+
+    rs = np.random.RandomState(seed)
+    w = rs.randint(0, 1 << 40, size=n, dtype=np.int64)
+    kind = rs.randint(0, 20, size=n)
+    w[kind < 2] = 0
+    w[(kind >= 2) & (kind < 4)] = 1
+    w[kind >= 15] *= -1
+    return w
+
+
+def _i64_to_be32(w, R):
+    """Value.ToFieldElement (curve.go:17-19) for a whole vector: v -> v mod r as big-endian rows."""
+    import numpy as np
+
+    n = len(w)
+    out = np.zeros((n, 32), dtype=np.uint8)
+    mag = np.abs(w).astype(np.uint64)
+    out[:, 24:] = mag.astype(">u8").view(np.uint8).reshape(n, 8)
+    neg = np.nonzero(w < 0)[0]
+    if len(neg):  # r - |v|: few distinct patterns would not help; do it with Python ints on the negative rows only
+        rows = [(R - int(m)).to_bytes(32, "big") for m in mag[neg]]
+        out[neg] = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(neg), 32)
+    return out
+
+
+@pytest.mark.parametrize("name,log2n", [("g1", 20), ("g2", 18)])
+def test_blind_eval_full_size_bit_exact_vs_oracle(ps_api, ctx, co, pr, name, log2n):
+    """BASELINE's size (2^20 G1 points; 2^18 for G2), bit-exact against the oracle's CPU Pippenger on the
+    same inputs: uniform 255-bit scalars and the int64 witness regime (zeros, ones, negatives -- the
+    short-scalar plan with folded signs and the heavy-bucket path).  The points are the oracle's own
+    synthetic vector (k0 + i q) G, uploaded as bytes."""
+    gid, og = _grp(ps_api, co, name)
+    n = 1 << log2n
+    threads = min(os.cpu_count() or 1, 16)
+    raw = og.gen_points(0x1234567, 0x89ABCDEF, n)
+    pts = ps_api.Points.upload(ctx, gid, raw)
+    sc = _uniform_be32(n, 2020 + log2n).tobytes()
+    assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == og.to_b(og.msm_pippenger(sc, raw, n, threads))
+    w = _witness_i64(n, 3030 + log2n)
+    got = ps_api.Poly.from_values(ctx, w.tolist()).BlindEval(pts)
+    assert ctx.last_msm_info()["windows"] * ctx.last_msm_info()["window_bits"] < 128  # the short plan was taken
+    assert got == og.to_b(og.msm_pippenger(_i64_to_be32(w, pr.R).tobytes(), raw, n, threads))
+
+
+def test_config4_2pow24_points_in_8_index_range_shards(ps_api, ctx, co, pr):
+    """BASELINE config #4 on one GPU: a 2^24-point G1 MSM as the 8 index-range shards that 8 ranks would
+    take (playsnark_amd.dist.shard_range), folded with ps_points_sum exactly as after the all_gather --
+    equal to the unsharded sum and, bit for bit, to the oracle's CPU Pippenger over the same 2^24 inputs.
+    PS_SKIP_ORACLE_2P24=1 drops the 20-second CPU leg."""
+    from playsnark_amd.dist import shard_range
+
+    n, world = 1 << 24, 8
+    seeds = ps_api.Poly.upload(ctx, _uniform_be32(n, 4040).tobytes())
+    pts = ps_api.Points.from_scalars(ctx, ps_api.G1, seeds)
+    del seeds
+    sc_bytes = _uniform_be32(n, 5050).tobytes()
+    sc = ps_api.Poly.upload(ctx, sc_bytes)
+    whole = sc.BlindEval(pts)
+    assert ctx.last_msm_info()["entries"] > 15 * n  # every scalar went through all of its windows
+    parts = b""
+    for g in range(world):
+        first, cnt = shard_range(n, g, world)
+        assert cnt == n // world
+        ps_api.msm_launch(ctx, pts.slice(first, cnt), sc.slice(first, cnt))
+        parts += ps_api.msm_finish(ctx, ps_api.G1)
+    assert ps_api.points_sum(ps_api.G1, parts) == whole
+    if os.environ.get("PS_SKIP_ORACLE_2P24") != "1":
+        raw = pts.download()
+        assert whole == co.G1.to_b(co.G1.msm_pippenger(sc_bytes, raw, n, min(os.cpu_count() or 1, 16)))
+
+
+def test_inputs_produced_between_launches_are_ordered(ps_api, ctx, co, pr):
+    """ps_points_from_scalars / ps_scalars_from_device_be32 return before their kernels have run; a sum
+    launched on a worker stream later in the same burst must still see their output."""
+    import torch
+
+    rng = _rng(pr, 4711)
+    n = 1 << 16
+    raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
+    sc_bytes = _uniform_be32(n, 6060).tobytes()
+    sc = ps_api.Poly.upload(ctx, sc_bytes)
+    ptsA = ps_api.Points.upload(ctx, ps_api.G1, raw)
+    wantA = co.G1.to_b(co.G1.msm_pippenger(sc_bytes, raw, n, 8))
+    ks = _uniform_be32(n, 7070)
+    dev = torch.from_numpy(ks).cuda()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ps_api.msm_launch(ctx, ptsA, sc)                                 # the context's own stream is busy now
+        k2 = ps_api.Poly.from_device_be32(ctx, dev.data_ptr(), n)        # asynchronous, on the context stream
+        p2 = ps_api.Points.from_scalars(ctx, ps_api.G1, k2)              # asynchronous as well
+        ps_api.msm_launch(ctx, p2, k2)                                   # runs on a worker stream
+        assert ps_api.msm_finish(ctx, ps_api.G1) == wantA
+        got = ps_api.msm_finish(ctx, ps_api.G1)
+        del p2, k2
+    # sum_i k_i (k_i G) = (sum k_i^2) G
+    tot = sum(int.from_bytes(ks[i].tobytes(), "big") ** 2 for i in range(n)) % pr.R
+    assert got == co.G1.to_b(co.G1.mul(tot))
+
+
+def test_sum_too_long_for_the_32bit_sort_offsets_is_refused(ps_api, ctx):
+    """windows x length >= 2^32 would wrap the u32 offsets of the counting sort: PS_ERR_ARG, not a wrong point.
+    Forced 4-bit windows (64 of them) reach the limit at 2^26 scalars."""
+    import torch
+
+    n = 1 << 26
+    dev = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    k = ps_api.Poly.from_device_be32(ctx, dev.data_ptr(), n)
+    pts = ps_api.Points.from_scalars(ctx, ps_api.G1, k)
+    ctx.set_window(4)
+    try:
+        with pytest.raises(ps_api.PlaysnarkError) as e:
+            ps_api.msm_launch(ctx, pts, k)
+        assert e.value.code == -5 and "32-bit" in str(e.value)
+        with pytest.raises(ps_api.PlaysnarkError):
+            ps_api.msm_multi(ctx, [pts, pts], k)
+    finally:
+        ctx.set_window(0)
+    half = k.slice(0, n // 2 - 1)
+    ctx.set_window(4)
+    try:
+        assert half.BlindEval(pts.slice(0, n // 2 - 1)) == b"\x40" + bytes(95)  # just under the limit: runs (all-zero scalars)
+    finally:
+        ctx.set_window(0)
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_points_subgroup_check_on_the_device(ps_api, ctx, co, pr, name, off_subgroup):
+    gid, og = _grp(ps_api, co, name)
+    good = og.gen_points(99, 101, 70) + og.to_b(None)
+    assert ps_api.Points.upload(ctx, gid, good).in_subgroup()
+    bad_pt = off_subgroup[0 if name == "g1" else 1]
+    bad = good[: 33 * og.nb] + og.to_b(bad_pt) + good[34 * og.nb :]
+    arr = ps_api.Points.upload(ctx, gid, bad)  # on the curve: the upload accepts it
+    assert not arr.in_subgroup()
+    assert arr.slice(0, 33).in_subgroup() and not arr.slice(33, 1).in_subgroup()
+    # the identity must be 0x40 followed by zeros
+    junk = bytearray(og.to_b(None))
+    junk[-1] = 1
+    with pytest.raises(ps_api.PlaysnarkError) as e:
+        ps_api.Points.upload(ctx, gid, bytes(junk))
+    assert e.value.code == -3

@@ -337,6 +337,33 @@ def test_sharded_phgr13_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
             assert getattr(folded, f) == getattr(whole, f), f
 
 
+def test_sharded_phgr13_refuses_keys_the_unsharded_prover_panics_on(ps_api, ctx, co, pr):
+    """A gsi longer than h, or evaluation-key arrays of different lengths, must not be silently truncated by the
+    index-range slices: BlindEval panics on them (algebra.go:350-352) and so does the sharded prover."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedPHGR13
+
+    rng = pr.SplitMix64(SEED + 556)
+    c, sol = rs.synthetic_circuit(20)
+    c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
+    q = _upload_circuit(ps_api, ctx, c)
+    ek, _vk = ps_api.NewPHGR13TrustedSetup(q, *[rng.fr() for _ in range(8)])
+    sol_dev = ps_api.Poly.upload(ctx, sol)
+    sh = ShardedPHGR13(ctx, None, 2, 0)
+    sh.partials(ek, q, sol_dev)  # the key as the setup made it is fine
+    good_gsi, good_vs = ek.gsi, ek.vs
+    ek.gsi = ps_api.Points.upload(ctx, ps_api.G1, good_gsi.download() + co.G1.to_b(co.G1.mul(5)))  # one point too many
+    with pytest.raises(ps_api.LengthMismatch):
+        sh.partials(ek, q, sol_dev)
+    with pytest.raises(ps_api.LengthMismatch):
+        ps_api.PHGR13Prove(ek, q, sol_dev)
+    ek.gsi = good_gsi
+    ek.vs = good_vs.slice(0, len(good_vs) - 1)
+    with pytest.raises(ps_api.LengthMismatch):
+        sh.partials(ek, q, sol_dev)
+    ek.vs = good_vs
+
+
 @pytest.mark.parametrize("world", [1, 3, 8])
 def test_sharded_groth16_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
     """The shares that `world` ranks compute with ps_groth16_prove_shard (index ranges of Xi, Xi2, NioLP,

@@ -3,8 +3,8 @@ CRS generated on the device (fixed-base kernel), checked at full size by the ref
 method -- recompute the discrete logs of A, B, C from the retained toxic waste
 (TestGroth16ProofGen, groth16_test.go:32-107) -- plus the QAP identity at a random point.
 
-Default n = 2^16 keeps the suite fast; PS_SCALE_LOG2N=20 runs BASELINE config #3 (n = 2^20) and
-prints the stage timings (used for DESIGN.md)."""
+Runs at n = 2^16 and at BASELINE's n = 2^20 (configs #3 and #5) by default; PS_SCALE_LOG2N=k runs that one
+size instead (e.g. 22) and prints the stage timings (used for DESIGN.md)."""
 import json
 import os
 import time
@@ -23,10 +23,14 @@ def _powers(x, n, shift, R):
     return out
 
 
-def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
+def _sizes():
+    return [int(os.environ["PS_SCALE_LOG2N"])] if "PS_SCALE_LOG2N" in os.environ else [16, 20]
+
+
+@pytest.mark.parametrize("log2n", _sizes())
+def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr, log2n):
     from oracle import restate as rs
 
-    log2n = int(os.environ.get("PS_SCALE_LOG2N", "16"))
     n = 1 << log2n
     R = pr.R
     rng = pr.SplitMix64(SEED + 2020)
@@ -85,7 +89,6 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     t0 = time.time()
     A_c, B_c, C_c, h = (p.download_bytes() for p in q.computeAggregatePoly(dsol))
     t["quotient_with_C_and_download_s"] = time.time() - t0
-    ev = lambda raw, cnt: co.lib().or_poly_eval  # noqa: E731  (placeholder to keep flake quiet)
     import ctypes as C
 
     def poly_eval_bytes(raw, cnt, at):
@@ -103,8 +106,9 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     b = (Bx + s * delta + beta) % R
     assert proof.A == one(co.G1, a)
     assert proof.B == one(co.G2, b)
-    res = sum((w[i] + beta * u[i] + alpha * v[i]) % R * pr.fr_div(sol[i], delta) for i in range(diff, m)) % R
-    res = (res + pr.fr_div(hx * zx % R, delta)) % R
+    # sum_i (w_i + beta u_i + alpha v_i) sol_i / delta: one inversion for the whole sum
+    res = sum((w[i] + beta * u[i] + alpha * v[i]) * sol[i] for i in range(diff, m)) % R
+    res = pr.fr_div((res + hx * zx) % R, delta)
     cd = (res + s * a + r * b - r * s % R * delta) % R
     assert proof.C == one(co.G1, cd)
     progress("Groth16 discrete-log checks")
@@ -144,7 +148,8 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr):
     print("SCALE " + json.dumps({"log2n": log2n, "n_vars": m, **{k: (round(val, 4) if isinstance(val, float) else val) for k, val in t.items()}}))
 
 
-def test_provers_on_a_booleanity_circuit_with_an_int64_witness(ps_api, ctx, co, pr):
+@pytest.mark.parametrize("log2n", _sizes())
+def test_provers_on_a_booleanity_circuit_with_an_int64_witness(ps_api, ctx, co, pr, log2n):
     """The regime the reference itself lives in: Vector = []int (algebra.go:13).  2^k booleanity gates
     b*b = b, a witness of random bits uploaded as int64: the solution sums take the short-scalar plan
     (and the heavy-bucket path: half the entries fall into one bucket).  Checks: both proofs are accepted
@@ -152,7 +157,6 @@ def test_provers_on_a_booleanity_circuit_with_an_int64_witness(ps_api, ctx, co, 
     from the same witness uploaded as 32-byte field elements (the 255-bit plan)."""
     from oracle import restate as rs
 
-    log2n = int(os.environ.get("PS_SCALE_LOG2N", "16"))
     n = 1 << log2n
     rng = pr.SplitMix64(SEED + 3030)
     c, wit = rs.bit_circuit(n)

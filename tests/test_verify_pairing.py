@@ -110,8 +110,30 @@ def test_product_pairing_is_bilinear_host_only(co, pr):
     assert api.pairing_equal(co.G1.to_b(None), g2(5), g1(7), co.G2.to_b(None))  # identity pairs to one
 
 
+def test_product_pairing_refuses_points_outside_the_subgroup(co, pr, off_subgroup):
+    """Untrusted points must be canonical, on the curve AND of order r (kyber's UnmarshalBinary rejects the
+    rest [upstream]; the Miller loop and the signed-digit folding assume order r).  Host-only: runs without a GPU."""
+    from playsnark_amd import api
+
+    g1 = lambda k: co.G1.to_b(co.G1.mul(k))
+    g2 = lambda k: co.G2.to_b(co.G2.mul(k))
+    bad1, bad2 = co.G1.to_b(off_subgroup[0]), co.G2.to_b(off_subgroup[1])
+    assert api.pairing_equal(g1(6), g2(35), g1(210), g2(1))
+    for args in ((bad1, g2(3), g1(3), g2(1)), (g1(3), bad2, g1(3), g2(1)), (g1(3), g2(1), bad1, g2(1)), (g1(3), g2(1), g1(3), bad2)):
+        with pytest.raises(api.PlaysnarkError) as e:
+            api.pairing_equal(*args)
+        assert e.value.code == -3 and "subgroup" in str(e.value)
+    inf_junk = bytearray(co.G1.to_b(None))
+    inf_junk[50] = 7  # "identity" with non-zero trailing bytes
+    with pytest.raises(api.PlaysnarkError) as e:
+        api.pairing_equal(bytes(inf_junk), g2(3), g1(3), g2(1))
+    assert e.value.code == -3
+    with pytest.raises(api.PlaysnarkError):
+        api.points_sum(api.G1, bytes(inf_junk))
+
+
 @pytest.mark.gpu
-def test_product_verifiers_accept_and_reject(ps_api, ctx, co, pr):
+def test_product_verifiers_accept_and_reject(ps_api, ctx, co, pr, off_subgroup):
     """ps_groth16_verify / ps_phgr13_verify on GPU-made proofs: accept, and reject
     the tampered proofs / public inputs of TestPinocchioInvalidProof (pinocchio_test.go:243-276);
     the verdicts agree with the oracle's independent Python pairing."""
@@ -136,6 +158,17 @@ def test_product_verifiers_accept_and_reject(ps_api, ctx, co, pr):
     assert not verify(proof, ps_api.Poly.upload(ctx, bad_io))
     with pytest.raises(ps_api.LengthMismatch):
         verify(proof, ps_api.Poly.upload(ctx, sol[: diff - 1]))
+    # on-curve points of the wrong order are refused, in the proof and in the key (the soundness gap of an on-curve-only test)
+    bad1, bad2 = co.G1.to_b(off_subgroup[0]), co.G2.to_b(off_subgroup[1])
+    for forged in (ps_api.Groth16Proof(r, s, bad1, proof.B, proof.C), ps_api.Groth16Proof(r, s, proof.A, bad2, proof.C),
+                   ps_api.Groth16Proof(r, s, proof.A, proof.B, bad1)):
+        with pytest.raises(ps_api.PlaysnarkError) as e:
+            verify(forged, io)
+        assert e.value.code == -3
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, bad2, tr.Delta2, iolp, proof, io)
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, tr.Gamma, tr.Delta2, up(ps_api.G1, tr.IoLP[:96] + bad1 + tr.IoLP[192:]), proof, io)
 
     rng = pr.SplitMix64(SEED + 909)
     c, wit = rs.toy_circuit()
@@ -158,6 +191,13 @@ def test_product_verifiers_accept_and_reject(ps_api, ctx, co, pr):
         saved = getattr(pp, field)
         setattr(pp, field, rnd)
         assert not ps_api.PHGR13Verify(ctx, vkb, vs_io, ws_io, ys_io, pp, io), field
+        setattr(pp, field, saved)
+    for field, forged in (("wss", co.G2.to_b(off_subgroup[1])), ("hs", co.G1.to_b(off_subgroup[0]))):
+        saved = getattr(pp, field)
+        setattr(pp, field, forged)
+        with pytest.raises(ps_api.PlaysnarkError) as e:
+            ps_api.PHGR13Verify(ctx, vkb, vs_io, ws_io, ys_io, pp, io)
+        assert e.value.code == -3
         setattr(pp, field, saved)
     for key in ("bgamma2", "av", "ay"):  # pinocchio_test.go:265-276 (random VK element)
         tampered = dict(vkb)
