@@ -66,3 +66,41 @@ def off_subgroup(pr):
         x += 1
     assert pr.G1.on_curve(g1) and pr.G2.on_curve(g2)
     return g1, g2
+
+
+class _HipMem:
+    """Raw device buffers for the tests that hand the library a device pointer (ps_scalars_from_device_be32),
+    through the HIP runtime the library itself is linked to -- not through torch, whose bundled runtime cannot
+    initialise once another copy of libamdhip64 owns the process."""
+
+    def __init__(self):
+        import ctypes
+
+        self.C = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.live = []
+
+    def alloc(self, nbytes, data=None):
+        C = self.C
+        ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(ptr), C.c_size_t(nbytes)) == 0
+        self.live.append(ptr)
+        if data is None:
+            assert self.hip.hipMemset(ptr, 0, C.c_size_t(nbytes)) == 0
+        else:
+            assert len(data) == nbytes
+            assert self.hip.hipMemcpy(ptr, data, C.c_size_t(nbytes), 1) == 0  # hipMemcpyHostToDevice
+        assert self.hip.hipDeviceSynchronize() == 0
+        return ptr.value
+
+    def free_all(self):
+        for p in self.live:
+            self.hip.hipFree(p)
+        self.live = []
+
+
+@pytest.fixture
+def hipmem(ctx):
+    m = _HipMem()
+    yield m
+    m.free_all()

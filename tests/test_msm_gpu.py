@@ -491,11 +491,9 @@ def test_config4_2pow24_points_in_8_index_range_shards(ps_api, ctx, co, pr):
         assert whole == co.G1.to_b(co.G1.msm_pippenger(sc_bytes, raw, n, min(os.cpu_count() or 1, 16)))
 
 
-def test_inputs_produced_between_launches_are_ordered(ps_api, ctx, co, pr):
+def test_inputs_produced_between_launches_are_ordered(ps_api, ctx, co, pr, hipmem):
     """ps_points_from_scalars / ps_scalars_from_device_be32 return before their kernels have run; a sum
     launched on a worker stream later in the same burst must still see their output."""
-    import torch
-
     rng = _rng(pr, 4711)
     n = 1 << 16
     raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
@@ -504,11 +502,10 @@ def test_inputs_produced_between_launches_are_ordered(ps_api, ctx, co, pr):
     ptsA = ps_api.Points.upload(ctx, ps_api.G1, raw)
     wantA = co.G1.to_b(co.G1.msm_pippenger(sc_bytes, raw, n, 8))
     ks = _uniform_be32(n, 7070)
-    dev = torch.from_numpy(ks).cuda()
-    torch.cuda.synchronize()
+    dev = hipmem.alloc(32 * n, ks.tobytes())
     for _ in range(3):
         ps_api.msm_launch(ctx, ptsA, sc)                                 # the context's own stream is busy now
-        k2 = ps_api.Poly.from_device_be32(ctx, dev.data_ptr(), n)        # asynchronous, on the context stream
+        k2 = ps_api.Poly.from_device_be32(ctx, dev, n)                   # asynchronous, on the context stream
         p2 = ps_api.Points.from_scalars(ctx, ps_api.G1, k2)              # asynchronous as well
         ps_api.msm_launch(ctx, p2, k2)                                   # runs on a worker stream
         assert ps_api.msm_finish(ctx, ps_api.G1) == wantA
@@ -519,15 +516,11 @@ def test_inputs_produced_between_launches_are_ordered(ps_api, ctx, co, pr):
     assert got == co.G1.to_b(co.G1.mul(tot))
 
 
-def test_sum_too_long_for_the_32bit_sort_offsets_is_refused(ps_api, ctx):
+def test_sum_too_long_for_the_32bit_sort_offsets_is_refused(ps_api, ctx, hipmem):
     """windows x length >= 2^32 would wrap the u32 offsets of the counting sort: PS_ERR_ARG, not a wrong point.
     Forced 4-bit windows (64 of them) reach the limit at 2^26 scalars."""
-    import torch
-
     n = 1 << 26
-    dev = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
-    torch.cuda.synchronize()
-    k = ps_api.Poly.from_device_be32(ctx, dev.data_ptr(), n)
+    k = ps_api.Poly.from_device_be32(ctx, hipmem.alloc(32 * n), n)
     pts = ps_api.Points.from_scalars(ctx, ps_api.G1, k)
     ctx.set_window(4)
     try:
