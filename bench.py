@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus > 1 (gloo + PS_BENCH_DEVICE=0 rehearses the multi-rank "
                          "path on a one-GPU box; the driver's runs use nccl = RCCL)")
+    ap.add_argument("--table-window", type=int, default=0, help="window bits of the table (0 = the library's choice)")
+    ap.add_argument("--no-table", action="store_true",
+                    help="do not build the window table 2^(c w) P of the resident points (ps_points_precompute): the plain plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (N = 1 only)")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="CPU baseline: at most 2^k of the GPU's points (default: the full 2^20 workload)")
@@ -265,6 +268,8 @@ def main():
     a = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 1000 + rank).tobytes())
     gid = api.G1 if g == "g1" else api.G2
     points = api.Points.from_scalars(ctx, gid, a)
+    if not args.no_table and not args.window:  # the CRS is fixed across proofs: its window table is built once, like the upload
+        points.precompute(args.table_window)
     if args.scalars == "uniform":
         host_scalars = uniform_scalars_be32(n, SEED + 2000 + rank).tobytes()
         scalars = api.Poly.upload(ctx, host_scalars)
@@ -368,6 +373,8 @@ def main():
                 "points_per_gpu": n,
                 "window_bits": c,
                 "windows": W,
+                "window_table": bool(points.table_window) and not args.window,
+                "window_table_bytes": (255 // points.table_window + 1) * n * (128 if g == "g1" else 256) if points.table_window else 0,
                 "slice": info["slice"],
                 "in_flight": args.in_flight,
                 "sharding": "index range per rank, all_gather of %d-B partial sums" % (96 if g == "g1" else 192) if world > 1 else "single GPU",
@@ -427,6 +434,8 @@ def extras(api, ctx, args):
     def msm_ms(gid, n, seed, steps, witness=False, in_flight=3):
         a = api.Poly.upload(ctx, uniform_scalars_be32(n, seed).tobytes())
         pts = api.Points.from_scalars(ctx, gid, a)
+        if not args.no_table and not args.window:
+            pts.precompute(args.table_window)
         a.free()
         sc = (api.Poly.from_values(ctx, witness_values(n, seed + 1).tolist()) if witness
               else api.Poly.upload(ctx, uniform_scalars_be32(n, seed + 1).tobytes()))

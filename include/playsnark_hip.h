@@ -61,6 +61,17 @@ void* ps_ctx_stream(ps_ctx* ctx);
  * ps_points_check_subgroup, as kyber's UnmarshalBinary would have rejected such points [upstream]. */
 int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts, size_t n, int fmt,
                      ps_points** out);
+/* Window table of a resident array: T[w][i] = 2^(c w) P[i] for every window w of a c-bit signed-digit
+ * decomposition (c = window_bits; 0 picks it from the array length: 20 at 2^20 points, 13 windows).  CRS arrays are
+ * fixed across proofs (groth16.go:30-61, pinochio.go:37-62), so the table is built once; every later sum over
+ * the array -- or over a ps_points_slice of it -- then lets all its windows share ONE bucket set: 13 instead of
+ * 16 bucket additions per 255-bit scalar and a sixteenth of the buckets to reduce.  Results are the same group
+ * elements, bit for bit.  Costs (255 / c + 1) rows of 128 B (G1) / 256 B (G2) per point in device memory (1.7 GB for
+ * 2^20 G1 points at c = 20);
+ * at most 2^26 - 1 points.  Sums fall back to the plain path when a table is absent, when ps_msm_set_window
+ * forces a window size, or when the arrays of a ps_msm_multi call do not all carry tables of one window size. */
+int ps_points_precompute(ps_ctx* ctx, ps_points* p, int window_bits);
+int ps_points_table_window(const ps_points* p); /* window bits of the table, 0 = none */
 /* *ok = 1 iff [r]P = O for every point of the array (GPU, ~400 group operations per point). */
 int ps_points_check_subgroup(ps_ctx* ctx, const ps_points* p, int* ok);
 /* out[i] = scalars[i] * G (fixed base).  GeneratePowersCommit (algebra.go:371-384) and the

@@ -22,7 +22,7 @@ SYMBOLS = [
     "ps_last_error", "ps_version", "ps_device_count",
     "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream",
     "ps_points_upload", "ps_points_from_scalars", "ps_points_download", "ps_points_download_fmt", "ps_points_len", "ps_points_group",
-    "ps_points_slice", "ps_points_free", "ps_points_check_subgroup",
+    "ps_points_slice", "ps_points_free", "ps_points_check_subgroup", "ps_points_precompute", "ps_points_table_window",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
@@ -120,6 +120,8 @@ def _load():
     lib.ps_points_group.argtypes = [vp]
     lib.ps_points_slice.argtypes = [vp, sz, sz, pp]
     lib.ps_points_check_subgroup.argtypes = [vp, vp, C.POINTER(C.c_int)]
+    lib.ps_points_precompute.argtypes = [vp, vp, i]
+    lib.ps_points_table_window.argtypes = [vp]
     lib.ps_points_free.argtypes = [vp]
     lib.ps_points_free.restype = None
     lib.ps_scalars_upload.argtypes = [vp, C.c_char_p, sz, pp]

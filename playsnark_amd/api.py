@@ -182,6 +182,16 @@ class Points:
         _check(lib.ps_points_slice(self._h, first, n, C.byref(h)))
         return Points(self.ctx, h, owner=self)
 
+    def precompute(self, window_bits: int = 0) -> "Points":
+        """Build the window table 2^(c w) P of this resident array once (ps_points_precompute): later sums over it,
+        or over slices of it, share one bucket set.  Returns self."""
+        _check(lib.ps_points_precompute(self.ctx._h, self._h, window_bits))
+        return self
+
+    @property
+    def table_window(self) -> int:
+        return lib.ps_points_table_window(self._h)
+
     def in_subgroup(self) -> bool:
         """[r]P = O for every point (what kyber's UnmarshalBinary enforces on the Go side [upstream])."""
         ok = C.c_int(0)

@@ -76,7 +76,7 @@ struct ps_ctx {
     hipEvent_t ev_acc_local = nullptr, ev_tail_done = nullptr;
     bool tail_used = false;
     // MSM workspace
-    DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts;
+    DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts, coarse;
     DevBuf staging;                  // byte staging for uploads / downloads
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -125,10 +125,16 @@ struct Storage {  // shared device allocation behind slices
     // Recorded by a producer that returns before its kernel has run (ps_points_from_scalars,
     // ps_scalars_from_device_be32); every stream that consumes the array waits for it first.
     hipEvent_t ready = nullptr;
+    // ps_points_precompute: window table T[w][i] = 2^(table_c * w) * P[i], w < table_W, rows of table_stride points
+    void* table = nullptr;
+    int table_c = 0, table_W = 0;
+    size_t table_stride = 0;
+    size_t count = 0;  // elements in the allocation (point arrays)
 };
 static void storage_unref(Storage* s) {
     if (s && --s->refs == 0) {
         if (s->ready) (void)hipEventDestroy(s->ready);
+        if (s->table) (void)hipFree(s->table);
         if (s->p) (void)hipFree(s->p);
         delete s;
     }
@@ -211,7 +217,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
-                      &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+                      &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->coarse, &c->staging, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
     if (c->g16_pa) ps_points_free(c->g16_pa);
@@ -355,6 +361,7 @@ static int points_alloc(ps_ctx* c, int group, size_t n, ps_points** out) {
         delete st;
         return fail(PS_ERR_HIP, std::string("hipMalloc points: ") + hipGetErrorString(e));
     }
+    st->count = n;
     *out = new ps_points{group, n, st, 0, c->device};
     return PS_OK;
 }
@@ -493,6 +500,65 @@ extern "C" void ps_points_free(ps_points* p) {
     storage_unref(p->st);
     delete p;
 }
+
+// Window table of a resident array (see k_table_next).  Built for the whole allocation behind `p`, so slices
+// of it (index-range shards) use it too.
+static inline size_t table_row_bytes(int group) { return group == PS_G1 ? 128 : 256; }  // one / two HBM lines per point
+static int table_window_for(size_t n) {
+    int best = 8;
+    double best_cost = 1e300;
+    for (int c = 8; c <= 22; c++) {
+        const int W = 255 / c + 1;
+        // All windows share one bucket set, so a top window that covers only a few bits would pile its n digits onto a
+        // few buckets (c = 19: 8 bits, a million entries on 116 buckets): only window sizes whose top window spans at
+        // least 2^-6 of the buckets are candidates (8, 9, 10, 13, 16, 20).
+        if (255 - c * (W - 1) < c - 6) continue;
+        const double cost = (double)n * W * 10.0 + (double)(1u << (c - 1)) * 42.0;
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+template <class F>
+static int build_table(ps_ctx* c, Storage* st, int group, int wbits, int W) {
+    const size_t n = st->count;
+    const u32 rb = (u32)table_row_bytes(group);
+    char* tab = (char*)st->table;
+    // row 0: the points themselves (zero doublings), re-laid out in padded rows
+    hipLaunchKernelGGL(k_table_next<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const char*)st->p, (u32)sizeof(Affine<F>), tab, rb, (u32)n, 0);
+    for (int w = 1; w < W; w++)
+        hipLaunchKernelGGL(k_table_next<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const char*)(tab + (size_t)(w - 1) * n * rb), rb,
+                           tab + (size_t)w * n * rb, rb, (u32)n, wbits);
+    HIP_TRY(hipGetLastError());
+    return PS_OK;
+}
+extern "C" int ps_points_precompute(ps_ctx* c, ps_points* p, int window_bits) {
+    if (!c || !p) return fail(PS_ERR_ARG, "ps_points_precompute: NULL argument");
+    if (window_bits != 0 && (window_bits < 8 || window_bits > 22)) return fail(PS_ERR_ARG, "ps_points_precompute: window bits must be 0 (automatic) or 8..22");
+    Storage* st = p->st;
+    const size_t n = st->count;
+    if (n == 0) return PS_OK;
+    if (n >= (1ull << ENTRY_W_SHIFT)) return fail(PS_ERR_ARG, "ps_points_precompute: at most 2^26 - 1 points per array (split it with ps_points_slice before uploading)");
+    HIP_TRY(hipSetDevice(c->device));
+    const int wbits = window_bits ? window_bits : table_window_for(n);
+    if (st->table && st->table_c == wbits) return PS_OK;
+    if (storage_wait_ready(st, c->stream)) return fail(PS_ERR_HIP, "ps_points_precompute: event wait failed");
+    if (st->table) {  // another window size: sums that may still read the old table are waited for
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(st->table);
+        st->table = nullptr;
+    }
+    const int W = 255 / wbits + 1;
+    hipError_t e = hipMalloc(&st->table, table_row_bytes(p->group) * n * (size_t)W);
+    if (e != hipSuccess) { st->table = nullptr; return fail(PS_ERR_HIP, std::string("hipMalloc window table: ") + hipGetErrorString(e)); }
+    int rc = p->group == PS_G1 ? build_table<Fp>(c, st, PS_G1, wbits, W) : build_table<Fp2>(c, st, PS_G2, wbits, W);
+    if (!rc && storage_mark_ready(st, c->stream)) rc = fail(PS_ERR_HIP, "ps_points_precompute: event record failed");
+    if (rc) { (void)hipStreamSynchronize(c->stream); (void)hipFree(st->table); st->table = nullptr; return rc; }
+    st->table_c = wbits;
+    st->table_W = W;
+    st->table_stride = n;
+    return PS_OK;
+}
+extern "C" int ps_points_table_window(const ps_points* p) { return p && p->st->table ? p->st->table_c : 0; }
 
 // Every point of the array in the order-r subgroup?  ([r]P on the device: ~400 group operations per point;
 // an opt-in check for arrays that arrive from outside -- ps_points_upload itself only tests the curve equation.)
@@ -634,28 +700,48 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     if (storage_wait_ready(sc->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced scalars
     int evi = 0;
     PS_STAGE_MARK();  // 0: start
-    HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
-    {
-        DigitConst cadd{};  // C = sum_{w < W-1} 2^(c*w + c-1)
-        for (int w = 0; w + 1 < pl.W; w++) {
-            int bit = w * pl.c + pl.c - 1;
-            if (bit < 256) cadd.w[bit >> 5] |= 1u << (bit & 31);
-        }
-        int bin_shift = 4;  // 16 counters = one 64-byte line
-        while ((pl.NB >> bin_shift) > (u32)DIGITS_BINS) bin_shift++;
-        dim3 grid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
-        hipLaunchKernelGGL(k_digits_grouped, grid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, scalars_ptr(sc),
-                           (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, sc->neg_small ? 1 : 0, (u32*)c->counts.p, (u32*)c->keys.p,
-                           (u32*)c->vals.p, (u32*)c->ranks.p);
+    DigitConst cadd{};  // C = sum_{w < W-1} 2^(c*w + c-1)
+    for (int w = 0; w + 1 < pl.W; w++) {
+        int bit = w * pl.c + pl.c - 1;
+        if (bit < 256) cadd.w[bit >> 5] |= 1u << (bit & 31);
     }
-    PS_STAGE_MARK();  // 1: after memset + digits
-    hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
-                       (u32*)c->bsum.p, (u64)G);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
-    hipLaunchKernelGGL(k_scan_add, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (u32*)c->offs.p, (const u32*)c->bsum.p, (u64)G);
-    PS_STAGE_MARK();  // 2: after scan
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->vals.p,
-                       (const u32*)c->ranks.p, (const u32*)c->offs.p, total, (u32*)c->sorted.p);
+    const dim3 dgrid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
+    const int fold_neg = sc->neg_small ? 1 : 0, single = pl.sets == 1 ? 1 : 0;
+    if (G <= SORT_MAX_BUCKETS) {  // two-level counting sort, no per-entry global atomics (msm.cuh 1'-3')
+        const u32 ncoarse = (u32)((G + SORT_FINE - 1) / SORT_FINE);
+        if ((rc = c->coarse.ensure(4 * (3 * (size_t)SORT_MAX_COARSE + 4)))) return rc;
+        u32* coarse_cnt = (u32*)c->coarse.p;
+        u32* coarse_off = coarse_cnt + SORT_MAX_COARSE + 1;
+        u32* coarse_cur = coarse_off + SORT_MAX_COARSE + 1;
+        HIP_TRY(hipMemsetAsync(coarse_cnt, 0, 4 * SORT_MAX_COARSE, st));
+        hipLaunchKernelGGL(k_sort_count, dgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
+                           single, ncoarse, (u32*)c->ranks.p, coarse_cnt);
+        PS_STAGE_MARK();  // 1: after digits + coarse histogram
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_MAX_COARSE), 0, st, (const u32*)coarse_cnt, ncoarse, coarse_off, coarse_cur,
+                           (u32*)c->offs.p + G);
+        hipLaunchKernelGGL(k_sort_partition, dgrid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, (const u32*)c->ranks.p,
+                           (u32)n, pl.NB, single, coarse_cur, (unsigned short*)c->keys.p, (u32*)c->vals.p);
+        PS_STAGE_MARK();  // 2: after scan + partition
+        hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)c->vals.p,
+                           (const u32*)coarse_off, (u32)G, (u32*)c->offs.p, (u32*)c->sorted.p);
+    } else {
+        HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
+        {
+            int bin_shift = 4;  // 16 counters = one 64-byte line
+            while ((pl.NB >> bin_shift) > (u32)DIGITS_BINS) bin_shift++;
+            hipLaunchKernelGGL(k_digits_grouped, dgrid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, scalars_ptr(sc),
+                               (u32)n, pl.c, pl.W, pl.NB, cadd, bin_shift, fold_neg, single, (u32*)c->counts.p, (u32*)c->keys.p,
+                               (u32*)c->vals.p, (u32*)c->ranks.p);
+        }
+        PS_STAGE_MARK();  // 1: after memset + digits
+        hipLaunchKernelGGL(k_scan_blocks, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (const u32*)c->counts.p, (u32*)c->offs.p,
+                           (u32*)c->bsum.p, (u64)G);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, (u32*)c->bsum.p, scan_tiles, (u32*)c->offs.p + G);
+        hipLaunchKernelGGL(k_scan_add, dim3(scan_tiles), dim3(SCAN_BLOCK), 0, st, (u32*)c->offs.p, (const u32*)c->bsum.p, (u64)G);
+        PS_STAGE_MARK();  // 2: after scan
+        hipLaunchKernelGGL(k_scatter, dim3(nblocks(total)), dim3(256), 0, st, (const u32*)c->keys.p, (const u32*)c->vals.p,
+                           (const u32*)c->ranks.p, (const u32*)c->offs.p, total, (u32*)c->sorted.p);
+    }
     PS_STAGE_MARK();  // 3: after scatter
     HIP_TRY(hipGetLastError());
     // entry count for introspection (read back with the window sums)
@@ -677,20 +763,27 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const u64 G = pl.G;
     const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
     const u32 segs_per_win = pl.NB >> RED_SEG_LOG;
-    const u32 nseg_total = segs_per_win * (u32)pl.W;
+    const u32 nseg_total = segs_per_win * (u32)pl.sets;
     const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
-    const u32 l2_jobs = (u32)pl.W * (u32)(red_bits + 1);
+    const u32 l2_jobs = (u32)pl.sets * (u32)(red_bits + 1);
+    // a reduction job sums segs_per_win (or half as many) points: more than 4096 are cut into pieces (k_reduce_l2b)
+    const u32 l2_split = segs_per_win > 8192 ? std::min<u32>(64u, segs_per_win / 4096u) : 1u;
+    const bool tab = pl.sets == 1;
+    const u32 pstride = tab ? (u32)table_row_bytes(pts->group) : (u32)sizeof(Affine<F>);
+    const char* src = tab ? (const char*)pts->st->table + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
+    const u32 idx_mask = tab ? (1u << ENTRY_W_SHIFT) - 1u : 0x7fffffffu;
+    const u64 w_stride = tab ? (u64)pts->st->table_stride : 0ull;
     int rc;
     if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
-    if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + l2_jobs)))) return rc;
-    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.W))) return rc;
+    if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + (size_t)l2_jobs * (l2_split + 1))))) return rc;
+    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.sets))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
     const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
-    if (sizeof(Xyzz<F>) * (size_t)pl.W > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
+    if (sizeof(Xyzz<F>) * (size_t)pl.sets > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
@@ -699,9 +792,10 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
     PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
-    hipLaunchKernelGGL(k_accumulate<KF>, dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, (const Affine<F>*)points_ptr(pts),
-                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, (Xyzz<F>*)wc->buckets.p,
-                       (Xyzz<F>*)wc->parts.p);
+    constexpr bool PF = LN == 1;  // G1: next point prefetched; the lane-pair G2 kernel has no registers to spare
+    hipLaunchKernelGGL((k_accumulate<KF, PF>), dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, src,
+                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, idx_mask, w_stride, pstride,
+                       (Xyzz<F>*)wc->buckets.p, (Xyzz<F>*)wc->parts.p);
     if (acc_done) HIP_TRY(hipEventRecord(acc_done, st));
     PS_STAGE_MARK();  // 5: after accumulate
     HIP_TRY(hipEventRecord(wc->ev_acc_local, st));
@@ -726,14 +820,18 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         Xyzz<F>* l2 = runs + nseg_total;
         hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
                            nseg_total, accs, runs);
-        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
-                           (const Xyzz<F>*)runs, segs_per_win, red_bits, l2);
-        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3((unsigned)pl.W), dim3(RED_L3_THREADS * LN), RED_L3_THREADS * sizeof(Xyzz<F>), st,
+        Xyzz<F>* pieces = l2 + l2_jobs;
+        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs * l2_split), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
+                           (const Xyzz<F>*)runs, segs_per_win, red_bits, l2_split, l2_split > 1 ? pieces : l2);
+        if (l2_split > 1)
+            hipLaunchKernelGGL(k_reduce_l2b<KF>, dim3(l2_jobs), dim3(64 * LN), 64 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)pieces, red_bits,
+                               l2_split, l2);
+        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3((unsigned)pl.sets), dim3(RED_L3_THREADS * LN), RED_L3_THREADS * sizeof(Xyzz<F>), st,
                            (const Xyzz<F>*)l2, red_bits, (Xyzz<F>*)wc->wins.p);
     }
     PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * pl.W,
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * pl.sets,
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(wc->ev_tail_done, st));
     wc->tail_used = true;
@@ -743,8 +841,17 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
 
 // Plan of a sum on context `c`.  Entry offsets, ranks and totals are 32-bit (k_scan_*, k_scatter, the sorted
 // list): a sum whose W * n digits would not fit is refused rather than wrapped (W = 16 windows: n < 2^28).
-static int msm_plan_checked(const ps_ctx* c, size_t n, int max_bits, MsmPlan* out) {
-    MsmPlan pl = msm_plan(n, max_bits, c->forced_c);
+static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int max_bits) {
+    const Storage* st = pts->st;
+    // a forced window size means "the plain path with this c" (A/B runs); entries keep 26 bits for the index
+    return st->table && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
+}
+static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t k, size_t n, int max_bits, MsmPlan* out) {
+    // The window-table plan needs every array of the call to carry a table for the same window size
+    bool tab = k > 0;
+    for (size_t i = 0; i < k && tab; i++)
+        tab = table_usable(c, pts[i], n, max_bits) && pts[i]->st->table_c == pts[0]->st->table_c;
+    MsmPlan pl = tab ? msm_plan_table(n, max_bits, pts[0]->st->table_c) : msm_plan(n, max_bits, c->forced_c);
     if (c->forced_slice) pl.M = c->forced_slice;
     if ((u64)pl.W * (u64)n >= (1ull << 32))
         return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +
@@ -767,7 +874,7 @@ template <class F>
 static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) {
     const Xyzz<F>* wins = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
     Xyzz<F> acc = xyzz_identity<F>();
-    for (int w = pl.W - 1; w >= 0; w--) {
+    for (int w = pl.sets - 1; w >= 0; w--) {  // one set (window table): the sum itself
         for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
         xyzz_add<F>(acc, wins[w]);
     }
@@ -850,7 +957,7 @@ extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, co
     }
     HIP_TRY(hipSetDevice(c->device));
     MsmPlan pl;
-    if ((rc = msm_plan_checked(c, sc->n, sc->max_bits, &pl))) return rc;
+    if ((rc = msm_plan_checked(c, pts, k, sc->n, sc->max_bits, &pl))) return rc;
     if (k > 1 && !c->aux && (rc = ps_ctx_create(c->device, &c->aux))) return rc;
     if (c->aux && c->aux->pending) return fail(PS_ERR_ARG, "ps_msm_multi: the auxiliary context is busy");
     if ((rc = msm_multi_launch(c, c, k > 1 ? c->aux : c, pts, k, sc, pl))) return rc;
@@ -897,7 +1004,7 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
         e = {pts->group, MsmPlan{}, wc};
     } else {
         MsmPlan pl;
-        int rc0 = msm_plan_checked(c, sc->n, sc->max_bits, &pl);
+        int rc0 = msm_plan_checked(c, &pts, 1, sc->n, sc->max_bits, &pl);
         if (rc0) return rc0;
         if (wc != c) HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
         // chain the accumulations: this one starts when the previously launched one is done

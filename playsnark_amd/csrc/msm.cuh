@@ -28,12 +28,16 @@ namespace ps {
 
 struct MsmPlan {
     int c;       // window bits
-    int W;       // windows
-    u32 NB;      // buckets per window = 2^(c-1)
-    u64 G;       // W * NB
+    int W;       // windows (digits per scalar)
+    u32 NB;      // buckets per bucket set = 2^(c-1)
+    u64 G;       // buckets in all: sets * NB
     int M;       // sorted entries per accumulation thread
     int SEG;     // buckets per reduction thread
+    int sets;    // bucket sets: W, or 1 when the points come with their window table 2^(c w) P (all windows share one set)
 };
+// Entries of the sorted list: point index | window << ENTRY_W_SHIFT | sign << 31.  The window field is used only
+// with a window table (then the index must fit ENTRY_W_SHIFT bits); without one the index may use all 31 bits.
+constexpr int ENTRY_W_SHIFT = 26;
 
 // cost model in field multiplications: N*W mixed adds (10) + G * (fix-up + 2 reduction adds) (42)
 static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
@@ -54,6 +58,7 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
         }
     }
     best.NB = 1u << (best.c - 1);
+    best.sets = best.W;
     best.G = (u64)best.W * best.NB;
     // entries per accumulation thread: 32 keeps ~2^19 threads busy at 2^20 points; larger inputs get
     // longer slices (same thread count), so a bucket of n / 2^(c-1) entries still spans only a few
@@ -63,6 +68,20 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     while (best.M < 1024 && total / (2 * (u64)best.M) >= (1u << 19)) best.M *= 2;
     best.SEG = 8;
     return best;
+}
+// Plan over a window table built for c-bit windows: one bucket set whatever the number of windows.
+static inline MsmPlan msm_plan_table(size_t n, int max_bits, int c) {
+    MsmPlan pl{};
+    pl.c = c;
+    pl.W = max_bits / c + 1;
+    pl.NB = 1u << (c - 1);
+    pl.sets = 1;
+    pl.G = pl.NB;
+    pl.M = 32;
+    const u64 total = (u64)n * pl.W;
+    while (pl.M < 1024 && total / (2 * (u64)pl.M) >= (1u << 19)) pl.M *= 2;
+    pl.SEG = 8;
+    return pl;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -93,7 +112,7 @@ __device__ inline u32 wave_incl_scan(u32 v);
 struct DigitConst { u32 w[8]; };  // the constant C above
 
 __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
-                                                                   DigitConst cadd, int bin_shift, int fold_neg,
+                                                                   DigitConst cadd, int bin_shift, int fold_neg, int single_set,
                                                                    u32* __restrict__ counts, u32* __restrict__ ent_key,
                                                                    u32* __restrict__ ent_val, u32* __restrict__ ent_rank) {
     __shared__ u32 hist[DIGITS_BINS];
@@ -169,6 +188,8 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
     hist[2 * tid] = ex;
     hist[2 * tid + 1] = ex + h0;
     __syncthreads();
+    const u32 wtag = single_set ? (u32)w << ENTRY_W_SHIFT : 0u;  // with a window table the entry names its window
+    const u32 key_base = single_set ? 0u : (u32)w * NB;          // ... and all windows share one bucket set
 #pragma unroll
     for (int j = 0; j < DIGITS_PER_THREAD; j++) {
         u32 code = dig[j];
@@ -176,7 +197,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
             u32 m1 = code & 0x7fffffffu;
             u32 pos = atomicAdd(&hist[m1 >> bin_shift], 1u);
             lkey[pos] = m1;
-            lval[pos] = (chunk_base + j * DIGITS_THREADS + tid) | (code & 0x80000000u);
+            lval[pos] = (chunk_base + j * DIGITS_THREADS + tid) | (code & 0x80000000u) | wtag;
         }
     }
     __syncthreads();
@@ -186,7 +207,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_digits_grouped(const u32* __
         const u32 p = p0 + tid;
         u32 key = 0xffffffffu, val = 0, rank = 0;
         const bool act = p < total;
-        if (act) { key = (u32)w * NB + lkey[p]; val = lval[p]; }
+        if (act) { key = key_base + lkey[p]; val = lval[p]; }
         // lanes that share a bucket are served by one atomic of their count: up to 8 rounds, each
         // serving the group of the first unserved lane (narrow top windows and skewed witnesses put a
         // whole wave into a handful of buckets); what is left goes one atomic per lane
@@ -312,6 +333,229 @@ __global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ ent_key
 }
 
 // ---------------------------------------------------------------------------------------
+// 1'-3'. The sort without per-entry global atomics (used whenever the bucket count G <= 2^20; the kernels
+// above remain for larger forced windows).  A returning atomic per entry on W * 2^(c-1) scattered counters
+// costs ~2e10/s chip-wide and collapses when all windows share ONE bucket set (window tables: every workgroup
+// hammers the same lines).  Two-level counting sort instead, most significant part first:
+//   k_sort_count      digits -> codes[w][i] (kept for the next kernel), LDS histogram of the coarse bin
+//                     key >> 10 per workgroup, one global add per (workgroup, non-empty bin)
+//   k_sort_scan       exclusive scan of the <= 1024 coarse bins
+//   k_sort_partition  entries grouped by coarse bin in LDS, one returning global add per (workgroup, bin)
+//                     reserves the run, coalesced writes of (fine key, value) into the bin's region
+//   k_sort_fine       one workgroup per coarse bin: LDS histogram of the 1024 fine keys, scan -> offs[],
+//                     second walk places the values: sorted[] and offs[] exactly as the old pipeline left them
+// ---------------------------------------------------------------------------------------
+constexpr int SORT_FINE_BITS = 10;
+constexpr u32 SORT_FINE = 1u << SORT_FINE_BITS;
+constexpr u32 SORT_MAX_COARSE = 1024;
+constexpr u64 SORT_MAX_BUCKETS = (u64)SORT_FINE * SORT_MAX_COARSE;
+static_assert(DIGITS_THREADS == (int)SORT_MAX_COARSE && SORT_FINE == SORT_MAX_COARSE, "one thread per histogram bin");
+
+// digit of scalar i in window w: (magnitude - 1) | sign << 31, or 0xffffffff for a zero digit (see k_digits_grouped)
+__device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, int W, int w, u32 NB, const DigitConst& cadd,
+                                 int fold_neg) {
+    const u32 mask = (1u << c) - 1u;
+    const int bit = w * c, li = bit >> 5, sh = bit & 31;
+    const bool top = w == W - 1;
+    u32 k[8];
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
+    uint4 a = sp[0], b = sp[1];
+    k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
+    u32 flip = 0;
+    if (fold_neg && k[7] != 0) {  // r - |v| of a negative witness value: |v| with the point negated
+        u32 borrow = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            u64 t = (u64)FrParams::mod(q) - k[q] - borrow;
+            k[q] = (u32)t;
+            borrow = (u32)(t >> 63);
+        }
+        flip = 0x80000000u;
+    }
+    u32 carry = 0;  // k' = k + C
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        u64 t = (u64)k[q] + cadd.w[q] + carry;
+        k[q] = (u32)t;
+        carry = (u32)(t >> 32);
+    }
+    u64 two = (u64)limb_sel8(k, li) | ((u64)limb_sel8(k, li + 1) << 32);
+    if (li == 7) two |= (u64)carry << 32;
+    u32 raw = top ? (u32)(two >> sh) : ((u32)(two >> sh) & mask);
+    int d = top ? (int)raw : (int)raw - (int)NB;
+    if (d == 0) return 0xffffffffu;
+    u32 mag = d < 0 ? (u32)(-d) : (u32)d;
+    return (mag - 1u) | ((d < 0 ? 0x80000000u : 0u) ^ flip);
+}
+
+// LDS counter updates with one shortcut: a wave whose active lanes all name the same counter (skewed scalars put
+// whole waves into one bucket) issues a single add instead of a 64-way conflict.  Must be called wave-uniformly.
+__device__ inline void lds_count(u32* ctr, u32 bin, bool active) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb);
+    if (same == act) {
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&ctr[lb], (u32)__popcll(act));
+    } else if (active) {
+        atomicAdd(&ctr[bin], 1u);
+    }
+}
+__device__ inline u32 lds_rank(u32* ctr, u32 bin, bool active) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return 0;
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = __ffsll((long long)act) - 1;
+    const u32 lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb);
+    u32 pos = 0;
+    if (same == act) {
+        u32 b0 = 0;
+        if (lane == leader) b0 = atomicAdd(&ctr[lb], (u32)__popcll(act));
+        b0 = __shfl(b0, leader, 64);
+        pos = b0 + (u32)__popcll(act & ((1ull << lane) - 1ull));
+    } else if (active) {
+        pos = atomicAdd(&ctr[bin], 1u);
+    }
+    return pos;
+}
+
+__global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
+                                                               DigitConst cadd, int fold_neg, int single_set, u32 ncoarse,
+                                                               u32* __restrict__ codes, u32* __restrict__ coarse_cnt) {
+    __shared__ u32 hist[SORT_MAX_COARSE];
+    const int w = blockIdx.y;
+    const u32 chunk_base = blockIdx.x * DIGITS_CHUNK;
+    const u32 tid = threadIdx.x;
+    hist[tid] = 0;  // DIGITS_THREADS == SORT_MAX_COARSE
+    __syncthreads();
+    const u32 key_base = single_set ? 0u : (u32)w * NB;
+#pragma unroll 4
+    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
+        const u32 i = chunk_base + j * DIGITS_THREADS + tid;
+        u32 code = 0xffffffffu;
+        if (i < n) {
+            code = digit_code(scalars, i, c, W, w, NB, cadd, fold_neg);
+            codes[(size_t)w * n + i] = code;
+        }
+        const bool act = code != 0xffffffffu;
+        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> SORT_FINE_BITS, act);
+    }
+    __syncthreads();
+    if (tid < ncoarse && hist[tid]) atomicAdd(&coarse_cnt[tid], hist[tid]);
+}
+
+// one workgroup: coarse_off = exclusive scan of coarse_cnt, coarse_cur = a copy (the partition kernel's cursors),
+// grand total -> coarse_off[ncoarse] and offs[G]
+__global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __restrict__ coarse_cnt, u32 ncoarse, u32* __restrict__ coarse_off,
+                                                               u32* __restrict__ coarse_cur, u32* __restrict__ offs_total) {
+    const u32 tid = threadIdx.x;
+    u32 total;
+    const u32 ex = block_excl_scan(tid < ncoarse ? coarse_cnt[tid] : 0u, &total);
+    if (tid < ncoarse) { coarse_off[tid] = ex; coarse_cur[tid] = ex; }
+    if (tid == 0) { coarse_off[ncoarse] = total; *offs_total = total; }
+}
+
+__global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set,
+                                                                   u32* __restrict__ coarse_cur, unsigned short* __restrict__ part_key,
+                                                                   u32* __restrict__ part_val) {
+    __shared__ u32 hist[SORT_MAX_COARSE], binstart[SORT_MAX_COARSE], gbase[SORT_MAX_COARSE];
+    __shared__ u32 wtot[DIGITS_THREADS / 64];
+    extern __shared__ __align__(16) unsigned char dg_smem[];
+    u32* lkey = reinterpret_cast<u32*>(dg_smem);
+    u32* lval = lkey + DIGITS_CHUNK;
+    const int w = blockIdx.y;
+    const u32 chunk_base = blockIdx.x * DIGITS_CHUNK;
+    const u32 tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    const u32 key_base = single_set ? 0u : (u32)w * NB;
+    const u32 wtag = single_set ? (u32)w << ENTRY_W_SHIFT : 0u;
+    u32 dig[DIGITS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
+        const u32 i = chunk_base + j * DIGITS_THREADS + tid;
+        const u32 code = i < n ? codes[(size_t)w * n + i] : 0xffffffffu;
+        dig[j] = code;
+        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> SORT_FINE_BITS, code != 0xffffffffu);
+    }
+    __syncthreads();
+    // exclusive scan of the 1024 bins, one per thread; reserve each non-empty bin's run in its global region
+    const u32 cnt = hist[tid];
+    const u32 inc = wave_incl_scan(cnt);
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    u32 before = 0, total = 0;
+    for (int q = 0; q < DIGITS_THREADS / 64; q++) {
+        const u32 t = wtot[q];
+        if (q < (int)(tid >> 6)) before += t;
+        total += t;
+    }
+    const u32 ex = before + inc - cnt;
+    __syncthreads();
+    binstart[tid] = ex;
+    hist[tid] = ex;  // now the bin's fill cursor
+    gbase[tid] = cnt ? atomicAdd(&coarse_cur[tid], cnt) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
+        const u32 code = dig[j];
+        const bool act = code != 0xffffffffu;
+        const u32 key = key_base + (code & 0x7fffffffu);
+        const u32 pos = lds_rank(hist, key >> SORT_FINE_BITS, act);
+        if (act) {
+            lkey[pos] = key;
+            lval[pos] = (chunk_base + j * DIGITS_THREADS + tid) | (code & 0x80000000u) | wtag;
+        }
+    }
+    __syncthreads();
+    for (u32 p = tid; p < total; p += DIGITS_THREADS) {
+        const u32 key = lkey[p], b = key >> SORT_FINE_BITS;
+        const u32 dst = gbase[b] + (p - binstart[b]);
+        part_key[dst] = (unsigned short)(key & (SORT_FINE - 1u));
+        part_val[dst] = lval[p];
+    }
+}
+
+__global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* __restrict__ part_key, const u32* __restrict__ part_val,
+                                                         const u32* __restrict__ coarse_off, u32 G, u32* __restrict__ offs,
+                                                         u32* __restrict__ sorted) {
+    __shared__ u32 hist[SORT_FINE];
+    __shared__ u32 wtot[SORT_FINE / 64];
+    const u32 p = blockIdx.x, tid = threadIdx.x;
+    const u32 lo = coarse_off[p], hi = coarse_off[p + 1];
+    hist[tid] = 0;
+    __syncthreads();
+    for (u32 i0 = lo; i0 < hi; i0 += SORT_FINE) {
+        const u32 i = i0 + tid;
+        const bool act = i < hi;
+        lds_count(hist, act ? (u32)part_key[i] : 0u, act);
+    }
+    __syncthreads();
+    const u32 cnt = hist[tid];
+    const u32 inc = wave_incl_scan(cnt);
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    u32 before = 0;
+    for (int q = 0; q < (int)(tid >> 6); q++) before += wtot[q];
+    const u32 start = lo + before + inc - cnt;
+    const u32 g = p * SORT_FINE + tid;
+    if (g < G) offs[g] = start;
+    __syncthreads();
+    hist[tid] = start;  // cursor
+    __syncthreads();
+    for (u32 i0 = lo; i0 < hi; i0 += SORT_FINE) {
+        const u32 i = i0 + tid;
+        const bool act = i < hi;
+        const u32 k = act ? (u32)part_key[i] : 0u;
+        const u32 v = act ? part_val[i] : 0u;
+        const u32 pos = lds_rank(hist, k, act);
+        if (act) sorted[pos] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // element access: the bucket kernels are written once over a *kernel field* KF and a storage
 // field.  Fp -> Fp (one lane per logical thread).  Fp2 storage -> Fp2s (two lanes per logical
 // thread, each lane loads / stores its own component of the same Fp2 records in HBM or LDS).
@@ -386,10 +630,23 @@ __device__ inline void flush_run(const Xyzz<KF>& acc, u32 g, u32 rs, u32 re, u32
     else st_xyzz<KF>(&parts[2 * (size_t)t + 1], acc);
 }
 
+// Point of a sorted entry.  A plain array is indexed by the entry's low 31 bits (w_stride = 0, rows of
+// sizeof(Affine) bytes); a window table [w][w_stride] by index + window * w_stride with the window in the entry's
+// bits ENTRY_W_SHIFT..30 and rows padded to `pstride` = 128 / 256 bytes, so that a point gathered at random from a
+// table far larger than the Infinity Cache costs one HBM line, not the two a 112-byte record usually straddles.
 template <class KF>
-__global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<typename FieldTraits<KF>::Store>* __restrict__ points,
+__device__ inline Affine<KF> ld_entry_point(const char* __restrict__ points, u32 e, u32 idx_mask, u64 w_stride, u32 pstride) {
+    const size_t row = (size_t)(e & idx_mask) + (size_t)((e >> ENTRY_W_SHIFT) & 31u) * w_stride;
+    return ld_affine<KF>(reinterpret_cast<const Affine<typename FieldTraits<KF>::Store>*>(points + row * pstride));
+}
+
+// PREFETCH: the next entry's point is requested before the current addition starts (28 more VGPRs), so that
+// the ~2 us of an HBM gather hide under the ~7 us of the addition even when both waves of a SIMD miss together.
+template <class KF, bool PREFETCH>
+__global__ void __launch_bounds__(256, 2) k_accumulate(const char* __restrict__ points,
                                                        const u32* __restrict__ sorted, const u32* __restrict__ offs,
-                                                       u32 G, int M, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                       u32 G, int M, u32 idx_mask, u64 w_stride, u32 pstride,
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts) {
     const u32 E = offs[G];
     const u32 t = logical_tid<KF>();
@@ -407,18 +664,31 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const Affine<typename Fie
     u32 bend = offs[g + 1];
     u32 run_start = start;
     Xyzz<KF> acc = xyzz_identity<KF>();
+    u32 e = sorted[start];
+    u32 e1 = start + 1 < end ? sorted[start + 1] : e;  // entries run two ahead of the additions, points one ahead
+    Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
     for (u32 p = start; p < end; p++) {
+        Affine<KF> nxt = pt;
+        u32 e2 = e1;
+        if (PREFETCH) {
+            if (p + 1 < end) nxt = ld_entry_point<KF>(points, e1, idx_mask, w_stride, pstride);
+            if (p + 2 < end) e2 = sorted[p + 2];
+        }
         if (p >= bend) {
             flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
             acc = xyzz_identity<KF>();
             run_start = p;
             do { g++; bend = offs[g + 1]; } while (bend <= p);
         }
-        u32 e = sorted[p];
-        Affine<KF> pt = ld_affine<KF>(&points[e & 0x7fffffffu]);
         if (!affine_is_identity<KF>(pt)) {
             if (e >> 31) pt.y = f_neg(pt.y);
             xyzz_madd<KF>(acc, pt.x, pt.y);
+        }
+        if (PREFETCH) {
+            pt = nxt; e = e1; e1 = e2;
+        } else if (p + 1 < end) {
+            e = sorted[p + 1];
+            pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
         }
     }
     flush_run<KF>(acc, g, run_start, end, start, t, offs, buckets, parts);
@@ -592,23 +862,29 @@ __global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldT
 template <class KF>
 __global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                    const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
-                                                   u32 segs_per_win, int nbits,
+                                                   u32 segs_per_win, int nbits, u32 nsplit,
                                                    Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    // grid = windows * (nbits + 1) jobs * nsplit: a job of a long window (one bucket set of 2^19 buckets has 65536
+    // segments) is cut into nsplit blocks so that no thread adds more than a few terms in a row; the pieces are
+    // summed, and the job's weight applied, by k_reduce_l2b.  nsplit == 1: the weight is applied here.
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 w = blockIdx.x / (u32)(nbits + 1), job = blockIdx.x % (u32)(nbits + 1);
+    const u32 split = blockIdx.x % nsplit, wj = blockIdx.x / nsplit;
+    const u32 w = wj / (u32)(nbits + 1), job = wj % (u32)(nbits + 1);
     const u32 lt = logical_local<KF>(), lb = logical_block<KF>();
     Xyzz<KF> acc = xyzz_identity<KF>();
     if (job == 0) {
-        for (u32 s = lt; s < segs_per_win; s += lb) {
+        const u32 chunk = segs_per_win / nsplit;
+        for (u32 s = split * chunk + lt; s < (split + 1) * chunk; s += lb) {
             Xyzz<KF> v = ld_xyzz<KF>(&accs[(size_t)w * segs_per_win + s]);
             xyzz_add_inl<KF>(acc, v);
         }
     } else {
         const int k = (int)job - 1;  // enumerate the s with bit k set: insert a 1 at position k of t
         const u32 low = (1u << k) - 1u;
-        for (u32 t = lt; t < (segs_per_win >> 1); t += lb) {
+        const u32 chunk = (segs_per_win >> 1) / nsplit;
+        for (u32 t = split * chunk + lt; t < (split + 1) * chunk; t += lb) {
             u32 s = ((t & ~low) << 1) | (1u << k) | (t & low);
             Xyzz<KF> v = ld_xyzz<KF>(&runs[(size_t)w * segs_per_win + s]);
             xyzz_add_inl<KF>(acc, v);
@@ -617,9 +893,27 @@ __global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTrai
     block_tree_sum<KF>(sm, acc);
     if (lt == 0) {  // weight of this job inside the window sum: 1 for job 0, 2^(k + RED_SEG_LOG) for T_k
         Xyzz<KF> v = ld_xyzz<KF>(&sm[0]);
-        const int shift = job == 0 ? 0 : (int)job - 1 + RED_SEG_LOG;
+        const int shift = (job == 0 || nsplit > 1) ? 0 : (int)job - 1 + RED_SEG_LOG;
         for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
         st_xyzz<KF>(&out[blockIdx.x], v);
+    }
+}
+
+// one block per (window, job): tree sum of the job's nsplit pieces (nsplit <= 64), then the job's weight
+template <class KF>
+__global__ void __launch_bounds__(128) k_reduce_l2b(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ pieces, int nbits,
+                                                    u32 nsplit, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
+    const u32 job = blockIdx.x % (u32)(nbits + 1), lt = logical_local<KF>();
+    Xyzz<KF> v = lt < nsplit ? ld_xyzz<KF>(&pieces[(size_t)blockIdx.x * nsplit + lt]) : xyzz_identity<KF>();
+    block_tree_sum<KF>(sm, v);
+    if (lt == 0) {
+        Xyzz<KF> r = ld_xyzz<KF>(&sm[0]);
+        const int shift = job == 0 ? 0 : (int)job - 1 + RED_SEG_LOG;
+        for (int i = 0; i < shift; i++) r = xyzz_dbl_inl<KF>(r);
+        st_xyzz<KF>(&out[blockIdx.x], r);
     }
 }
 
@@ -886,6 +1180,24 @@ __global__ void __launch_bounds__(256) k_fixed_base_table(Affine<F>* __restrict_
     Affine<F> out;
     if (!xyzz_to_affine<F>(acc, out.x, out.y)) { out.x = f_zero((const F*)0); out.y = f_zero((const F*)0); }
     table[idx] = out;
+}
+
+// Window table of a resident CRS array: next[i] = 2^c * prev[i] (affine in, affine out).  T[w] = 2^(c w) P lets
+// every window of a sum share ONE bucket set, which is what allows c = 20 (13 digits per 255-bit scalar instead of 16).
+template <class F>
+__global__ void __launch_bounds__(256) k_table_next(const char* __restrict__ prev, u32 prev_stride, char* __restrict__ next, u32 next_stride,
+                                                    u32 n, int c) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> a = *reinterpret_cast<const Affine<F>*>(prev + (size_t)i * prev_stride);
+    Affine<F> r;
+    r.x = f_zero((const F*)0); r.y = f_zero((const F*)0);
+    if (!(fp_all_zero(a.x) && fp_all_zero(a.y))) {
+        Xyzz<F> t = xyzz_from_affine<F>(a.x, a.y);
+        for (int k = 0; k < c; k++) t = xyzz_dbl<F>(t);
+        if (!xyzz_to_affine<F>(t, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
+    }
+    *reinterpret_cast<Affine<F>*>(next + (size_t)i * next_stride) = r;
 }
 
 // out[i] = a[i] + b[i] + c[i] (affine in, affine out; (0,0) is the identity)

@@ -123,8 +123,10 @@ def test_blind_eval_int64_witness_scalars(ps_api, ctx, co, pr, name):
     assert ctx.last_msm_info()["windows"] * ctx.last_msm_info()["window_bits"] < 128
 
 
-@pytest.mark.parametrize("c", [4, 5, 7, 11, 16])
+@pytest.mark.parametrize("c", [4, 5, 7, 11, 16, 18, 20])
 def test_window_size_does_not_change_the_result(ps_api, ctx, co, pr, c):
+    """Forced window sizes; 18 and 20 give more than 2^20 buckets, which takes the one-level sort with returning
+    atomics (k_digits_grouped / k_scatter) instead of the two-level counting sort."""
     rng = _rng(pr, 11)
     n = 777
     sc = [rng.fr() for _ in range(n)]
@@ -555,3 +557,93 @@ def test_points_subgroup_check_on_the_device(ps_api, ctx, co, pr, name, off_subg
     with pytest.raises(ps_api.PlaysnarkError) as e:
         ps_api.Points.upload(ctx, gid, bytes(junk))
     assert e.value.code == -3
+
+
+# ---- window tables (ps_points_precompute): the same sums, all windows in one bucket set ----
+@pytest.mark.parametrize("name", ["g1", "g2"])
+@pytest.mark.parametrize("n,wbits", [(1, 8), (5, 8), (333, 9), (1024, 12), (3000, 0)])
+def test_window_table_sums_equal_the_plain_sums(ps_api, ctx, co, pr, name, n, wbits):
+    """Same group element, bit for bit, as the plain path and the oracle: random scalars, the edge scalars 0 / 1 / r-1,
+    identity points, repeated points and P / -P pairs in one bucket, int64 witnesses with negative values, slices."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 31000 + n)
+    pts_list = og.unpack(og.gen_points(rng.fr(), rng.fr(), n))
+    if n >= 5:
+        P = pts_list[0]
+        negP = (P[0], (pr.P - P[1]) % pr.P) if name == "g1" else (P[0], ((-P[1][0]) % pr.P, (-P[1][1]) % pr.P))
+        pts_list[1], pts_list[2], pts_list[3] = P, negP, None
+    raw = og.pack(pts_list)
+    plain = ps_api.Points.upload(ctx, gid, raw)
+    tab = ps_api.Points.upload(ctx, gid, raw).precompute(wbits)
+    assert tab.table_window == (wbits or tab.table_window) and tab.table_window >= 8 and plain.table_window == 0
+    k = rng.fr()
+    vectors = [[rng.fr() for _ in range(n)], [k] * n, [0, 1, pr.R - 1, pr.R - 2, 2][:n] + [rng.fr() for _ in range(max(0, n - 5))]]
+    for sc in vectors:
+        want = og.to_b(og.blind_eval(sc, raw)) if n <= 64 else og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+        poly = ps_api.Poly.upload(ctx, sc)
+        got = poly.BlindEval(tab)
+        assert ctx.last_msm_info()["window_bits"] == tab.table_window and ctx.last_msm_info()["buckets"] == 1 << (tab.table_window - 1)
+        assert got == want and poly.BlindEval(plain) == want
+    vals = [0, 1, -1, 35, -(1 << 62), (1 << 63) - 1, -(1 << 63)][:n] + [int(rng.next() % 2000) - 1000 for _ in range(max(0, n - 7))]
+    assert ps_api.Poly.from_values(ctx, vals).BlindEval(tab) == og.to_b(og.blind_eval_i64(vals, raw))
+    if n >= 333:  # an index-range shard of a precomputed array uses the same table
+        first, cnt = n // 3, n // 2
+        sc = vectors[0]
+        got = ps_api.Poly.upload(ctx, sc[first:first + cnt]).BlindEval(tab.slice(first, cnt))
+        assert ctx.last_msm_info()["buckets"] == 1 << (tab.table_window - 1)
+        assert got == og.to_b(og.msm_pippenger(co.pack_fr(sc[first:first + cnt]), raw[first * og.nb:(first + cnt) * og.nb], cnt, 4))
+
+
+def test_window_table_in_the_queue_in_multi_sums_and_rebuilt(ps_api, ctx, co, pr):
+    """Tables in ps_msm_launch / ps_msm_finish bursts, in ps_msm_multi (all arrays with tables of one window size: the
+    table plan; otherwise the plain plan), with ps_msm_set_window forcing the plain path, and rebuilt for another size."""
+    rng = _rng(pr, 32000)
+    n = 700
+    sc = [rng.fr() for _ in range(n)]
+    poly = ps_api.Poly.upload(ctx, sc)
+    raws = [co.G1.gen_points(rng.fr(), rng.fr(), n), co.G2.gen_points(rng.fr(), rng.fr(), n), co.G1.gen_points(rng.fr(), rng.fr(), n)]
+    gids = [ps_api.G1, ps_api.G2, ps_api.G1]
+    ogs = [co.G1, co.G2, co.G1]
+    want = [og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4)) for og, raw in zip(ogs, raws)]
+    arrs = [ps_api.Points.upload(ctx, g, raw).precompute(10) for g, raw in zip(gids, raws)]
+    for a in arrs:
+        ps_api.msm_launch(ctx, a, poly)
+    assert [ps_api.msm_finish(ctx, g) for g in gids] == want
+    assert ps_api.msm_multi(ctx, arrs, poly) == want and ctx.last_msm_info()["buckets"] == 1 << 9
+    arrs[1].precompute(11)  # a different window size in the same call: the plain plan for all
+    assert ps_api.msm_multi(ctx, arrs, poly) == want and ctx.last_msm_info()["buckets"] > 1 << 10
+    assert poly.BlindEval(arrs[1]) == want[1] and ctx.last_msm_info()["window_bits"] == 11
+    ctx.set_window(7)
+    try:
+        assert poly.BlindEval(arrs[0]) == want[0] and ctx.last_msm_info()["window_bits"] == 7
+    finally:
+        ctx.set_window(0)
+    with pytest.raises(ps_api.PlaysnarkError):
+        arrs[0].precompute(5)
+
+
+def test_window_table_full_size_bit_exact_vs_oracle(ps_api, ctx, co, pr):
+    """2^20 G1 points with their table (c = 20: 13 windows, one set of 2^19 buckets, the split reduction jobs), uniform
+    and witness scalars, bit-exact against the oracle; c = 18 forced on 2^16 points for the same code path at a second size."""
+    n = 1 << 20
+    threads = min(os.cpu_count() or 1, 16)
+    raw = co.G1.gen_points(0x7654321, 0xFEDCBA9, n)
+    pts = ps_api.Points.upload(ctx, ps_api.G1, raw).precompute()
+    c = pts.table_window
+    assert c == 20  # the cost model's choice at this length (19 would leave an 8-bit top window)
+    sc = _uniform_be32(n, 8080).tobytes()
+    want = co.G1.to_b(co.G1.msm_pippenger(sc, raw, n, threads))
+    got = ps_api.Poly.upload(ctx, sc).BlindEval(pts)
+    info = ctx.last_msm_info()
+    assert (info["window_bits"], info["windows"], info["buckets"]) == (c, 255 // c + 1, 1 << (c - 1)) and info["entries"] < (255 // c + 1) * n
+    assert got == want
+    pts.precompute(19)  # a window size whose top window is nearly empty: a million entries on 116 buckets
+    assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want and ctx.last_msm_info()["window_bits"] == 19
+    pts.precompute(20)
+    w = _witness_i64(n, 9090)
+    got = ps_api.Poly.from_values(ctx, w.tolist()).BlindEval(pts)
+    assert ctx.last_msm_info()["windows"] == 4 and ctx.last_msm_info()["window_bits"] == 20
+    assert got == co.G1.to_b(co.G1.msm_pippenger(_i64_to_be32(w, pr.R).tobytes(), raw, n, threads))
+    m = 1 << 16
+    small = ps_api.Points.upload(ctx, ps_api.G1, raw[: 96 * m]).precompute(18)
+    assert ps_api.Poly.upload(ctx, sc[: 32 * m]).BlindEval(small) == co.G1.to_b(co.G1.msm_pippenger(sc[: 32 * m], raw[: 96 * m], m, threads))
