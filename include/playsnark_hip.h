@@ -72,6 +72,10 @@ int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts,
  * forces a window size, or when the arrays of a ps_msm_multi call do not all carry tables of one window size. */
 int ps_points_precompute(ps_ctx* ctx, ps_points* p, int window_bits);
 int ps_points_table_window(const ps_points* p); /* window bits of the table, 0 = none */
+/* ps_groth16_prove / ps_phgr13_prove build the tables of their CRS arrays themselves on first use (keys of at least
+ * 1024 points; cached per key; about 9 GB for a 2^20-constraint Groth16 key, 15 GB for a PHGR13 one).
+ * enable = 0 keeps the provers on the plain plan. */
+int ps_ctx_set_tables(ps_ctx* ctx, int enable);
 /* *ok = 1 iff [r]P = O for every point of the array (GPU, ~400 group operations per point). */
 int ps_points_check_subgroup(ps_ctx* ctx, const ps_points* p, int* ok);
 /* out[i] = scalars[i] * G (fixed base).  GeneratePowersCommit (algebra.go:371-384) and the
@@ -193,7 +197,7 @@ int ps_groth16_prove(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, cons
 /* One rank's share of Groth16Prove when the sums are sharded over `world` GPUs (one process each): rank g
  * takes its index range of every CRS array, rank 0 also the fixed points; A_part / B_part / C_part of all
  * ranks add up (ps_points_sum, after an all_gather) to the A, B, C of ps_groth16_prove.  Every rank
- * computes the quotient itself. */
+ * computes the quotient itself (beside its sums: the quotient runs on a stream of its own). */
 int ps_groth16_prove_shard(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, const ps_scalars* sol,
                            const uint8_t r_be32[32], const uint8_t s_be32[32], int rank, int world, uint8_t A_part[96],
                            uint8_t B_part[192], uint8_t C_part[96]);

@@ -20,7 +20,7 @@ PS_G1, PS_G2 = 1, 2
 # every symbol include/playsnark_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "ps_last_error", "ps_version", "ps_device_count",
-    "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream",
+    "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream", "ps_ctx_set_tables",
     "ps_points_upload", "ps_points_from_scalars", "ps_points_download", "ps_points_download_fmt", "ps_points_len", "ps_points_group",
     "ps_points_slice", "ps_points_free", "ps_points_check_subgroup", "ps_points_precompute", "ps_points_table_window",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
@@ -112,6 +112,7 @@ def _load():
     lib.ps_ctx_destroy.restype = None
     lib.ps_ctx_sync.argtypes = [vp]
     lib.ps_ctx_stream.argtypes = [vp]
+    lib.ps_ctx_set_tables.argtypes = [vp, i]
     lib.ps_points_upload.argtypes = [vp, i, C.c_char_p, sz, i, pp]
     lib.ps_points_from_scalars.argtypes = [vp, i, vp, pp]
     lib.ps_points_download.argtypes = [vp, vp, sz, sz, C.c_char_p]

@@ -72,6 +72,10 @@ class Context:
     def set_window(self, bits: int):
         _check(lib.ps_msm_set_window(self._h, bits))
 
+    def set_tables(self, enable: bool):
+        """Whether the provers build window tables for their CRS arrays (default: yes, for keys of >= 1024 points)."""
+        _check(lib.ps_ctx_set_tables(self._h, int(enable)))
+
     def set_slice(self, entries: int):
         _check(lib.ps_msm_set_slice(self._h, entries))
 

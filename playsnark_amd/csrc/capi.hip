@@ -96,6 +96,9 @@ struct ps_ctx {
     ps_ctx* last_chain = nullptr;    // workspace of the sum launched last (its ev_acc_local = accumulation done)
     ps_ctx* last_timed = nullptr;
     float phase_ms[PS_PROVE_PHASES] = {0, 0, 0, 0};  // host wall clock of the last prover call
+    bool use_tables = true;          // the provers build window tables for their CRS arrays (ps_ctx_set_tables)
+    void* d_small = nullptr;         // 256 B of device scratch for the provers' few loose scalars (r, s, rs, 1, 0)
+    hipEvent_t ev_q = nullptr;       // ordering between the context stream and the quotient's high-priority stream
     ps_msm_info last_info{};
     int forced_c = 0;
     int forced_slice = 0;
@@ -234,6 +237,8 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     for (auto& e : c->ev_acc) if (e) (void)hipEventDestroy(e);
     if (c->ev_sorted) (void)hipEventDestroy(c->ev_sorted);
     if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_acc_local) (void)hipEventDestroy(c->ev_acc_local);
     if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
@@ -964,7 +969,9 @@ extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, co
     return msm_multi_finish(c, c, pts, k, pl, out);
 }
 
-extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* sc) {
+// allow_self = false keeps the context's own stream out of the rotation (the provers run the quotient on it while
+// the sums run on the three worker contexts pipe, pipe2, aux)
+static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, bool allow_self) {
     if (!c || !pts || !sc) return fail(PS_ERR_ARG, "ps_msm: NULL argument");
     if (pts->n != sc->n)  // algebra.go:350-352
         return fail(PS_ERR_LENGTH, "mismatch of length between poly " + std::to_string(sc->n) + " and blinded eval points " +
@@ -972,9 +979,9 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
     if (c->q_len == PS_MSM_QUEUE) return fail(PS_ERR_ARG, "ps_msm_launch: PS_MSM_QUEUE sums are already pending on this context");
     HIP_TRY(hipSetDevice(c->device));
     // a workspace no pending sum is using: the context itself first
-    ps_ctx** slots[3] = {nullptr, &c->pipe, &c->pipe2};
+    ps_ctx** slots[4] = {nullptr, &c->pipe, &c->pipe2, &c->aux};
     ps_ctx* wc = nullptr;
-    for (int w = 0; w < 3 && !wc; w++) {
+    for (int w = allow_self ? 0 : 1; w < (allow_self ? 3 : 4) && !wc; w++) {
         ps_ctx* cand = w == 0 ? c : *slots[w];
         bool busy = false;
         for (int j = 0; j < c->q_len; j++) busy = busy || (cand && c->q[(c->q_head + j) % PS_MSM_QUEUE].wc == cand);
@@ -1018,6 +1025,7 @@ extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* 
     c->pending = true;
     return PS_OK;
 }
+extern "C" int ps_msm_launch(ps_ctx* c, const ps_points* pts, const ps_scalars* sc) { return msm_launch_impl(c, pts, sc, true); }
 
 extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
     if (!c || !out) return fail(PS_ERR_ARG, "ps_msm_finish: NULL argument");
@@ -1093,6 +1101,11 @@ extern "C" int ps_msm_last_stage_ms(ps_ctx* c, float* ms) {
 extern "C" int ps_prove_last_phase_ms(ps_ctx* c, float* ms) {
     if (!c || !ms) return fail(PS_ERR_ARG, "NULL argument");
     for (int i = 0; i < PS_PROVE_PHASES; i++) ms[i] = c->phase_ms[i];
+    return PS_OK;
+}
+extern "C" int ps_ctx_set_tables(ps_ctx* c, int enable) {
+    if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
+    c->use_tables = enable != 0;
     return PS_OK;
 }
 extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {
