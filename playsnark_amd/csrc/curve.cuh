@@ -110,12 +110,12 @@ PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
     F pp = f_sqr(p);
     F ppp = f_mul(p, pp);
     F q = f_mul(acc.x, pp);
-    // ZZ3, ZZZ3 first: PP and the old ZZ, ZZZ are dead before the widest product (Y3) starts
+    F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), q), q));
+    F y3 = f_norm(f_mul2sub(r, f_sub(q, x3), acc.y, ppp));  // classes 2*2 + 1*1
     acc.zz = f_mul(acc.zz, pp);
     acc.zzz = f_mul(acc.zzz, ppp);
-    F x3 = f_norm(f_sub(f_sub(f_sub(f_sqr(r), ppp), q), q));
-    acc.y = f_norm(f_mul2sub(r, f_sub(q, x3), acc.y, ppp));  // classes 2*2 + 1*1
     acc.x = x3;
+    acc.y = y3;
 }
 
 // acc += q (add-2008-s): 12M + 2S.  _inl is forced inline for the latency-bound reduction kernels

@@ -469,11 +469,11 @@ PS_INL Fp f_mul2add(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
     r.l[FP_L - 1] = (i32)acc;
     return r;
 }
-// a1*b1 + a2*b2 + a3*b3 + a4*b4 under ONE Montgomery reduction (980 multiply-adds instead of 2 x 588).
-// The 64-bit columns hold 14 terms of each product plus the reduction terms, so the operands' limb
-// classes must satisfy class(a1)class(b1) + .. + class(a4)class(b4) <= 8.
-PS_INL Fp f_mul4add(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, const Fp& a3, const Fp& b3, const Fp& a4,
-                    const Fp& b4) {
+// a1*b1 + a2*b2 - s1*t1 - s2*t2 under ONE Montgomery reduction: 980 multiply-adds instead of 2 x 588 (the lane-split
+// Fp2 form of a*b - c*d, below).  The 64-bit columns hold 14 terms of each product plus the reduction terms, so the
+// operands' limb classes must satisfy class(a1)class(b1) + .. + class(s2)class(t2) <= 8.
+PS_INL Fp f_mul2add2sub(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, const Fp& s1, const Fp& t1, const Fp& s2,
+                        const Fp& t2) {
     Fp r;
     i32 m[FP_L];
     i64 acc = 0;
@@ -483,8 +483,8 @@ PS_INL Fp f_mul4add(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, cons
         for (int i = 0; i <= k; i++) {
             acc += (i64)a1.l[i] * (i64)b1.l[k - i];
             acc += (i64)a2.l[i] * (i64)b2.l[k - i];
-            acc += (i64)a3.l[i] * (i64)b3.l[k - i];
-            acc += (i64)a4.l[i] * (i64)b4.l[k - i];
+            acc -= (i64)s1.l[i] * (i64)t1.l[k - i];
+            acc -= (i64)s2.l[i] * (i64)t2.l[k - i];
         }
 #pragma unroll
         for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
@@ -498,8 +498,8 @@ PS_INL Fp f_mul4add(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, cons
         for (int i = k - FP_L + 1; i < FP_L; i++) {
             acc += (i64)a1.l[i] * (i64)b1.l[k - i];
             acc += (i64)a2.l[i] * (i64)b2.l[k - i];
-            acc += (i64)a3.l[i] * (i64)b3.l[k - i];
-            acc += (i64)a4.l[i] * (i64)b4.l[k - i];
+            acc -= (i64)s1.l[i] * (i64)t1.l[k - i];
+            acc -= (i64)s2.l[i] * (i64)t2.l[k - i];
         }
 #pragma unroll
         for (int i = k - FP_L + 1; i < FP_L; i++) acc += (i64)m[i] * (i64)fp_mod28(k - i);
@@ -509,7 +509,6 @@ PS_INL Fp f_mul4add(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, cons
     r.l[FP_L - 1] = (i32)acc;
     return r;
 }
-
 
 // Out-of-line copy for code paths where ten inlined multiplications per group operation would
 // not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
@@ -965,15 +964,40 @@ struct Fp2s {
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ inline int pair_lane() { return (int)(threadIdx.x & 1u); }
-__device__ inline i32 pair_swap(i32 x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, false); }
+__device__ inline i32 pair_swap(i32 x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, false); }   // quad_perm [1,0,3,2]
+__device__ inline i32 pair_bcast0(i32 x) { return __builtin_amdgcn_mov_dpp(x, 0xA0, 0xF, 0xF, false); } // quad_perm [0,0,2,2]: the even lane's value
+__device__ inline i32 pair_bcast1(i32 x) { return __builtin_amdgcn_mov_dpp(x, 0xF5, 0xF, 0xF, false); } // quad_perm [1,1,3,3]: the odd lane's value
 #else  // host pass: never executed, present so that __device__ code parses
 PS_HD inline int pair_lane() { return 0; }
 PS_HD inline i32 pair_swap(i32 x) { return x; }
+PS_HD inline i32 pair_bcast0(i32 x) { return x; }
+PS_HD inline i32 pair_bcast1(i32 x) { return x; }
 #endif
 PS_INL Fp pair_swap(const Fp& a) {
     Fp r;
 #pragma unroll
     for (int i = 0; i < FP_L; i++) r.l[i] = pair_swap(a.l[i]);
+    return r;
+}
+PS_INL Fp pair_bcast0(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = pair_bcast0(a.l[i]);
+    return r;
+}
+PS_INL Fp pair_bcast1(const Fp& a) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = pair_bcast1(a.l[i]);
+    return r;
+}
+// the partner's component with the sign the complex product wants: even lane -a1, odd lane a0.  (x ^ m) - m negates
+// where m is all ones: one v_xad_u32 per limb, no select.
+PS_INL Fp pair_cross(const Fp& a) {
+    const u32 m = pair_lane() ? 0u : 0xffffffffu;
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < FP_L; i++) r.l[i] = (i32)(((u32)pair_swap(a.l[i]) ^ m) - m);
     return r;
 }
 PS_INL Fp2s f_zero(const Fp2s*) { return Fp2s{fp_zero()}; }
@@ -984,18 +1008,12 @@ PS_INL Fp2s f_neg(const Fp2s& a) { return Fp2s{f_neg(a.v)}; }
 PS_INL Fp2s f_dbl(const Fp2s& a) { return Fp2s{f_add(a.v, a.v)}; }
 PS_INL Fp2s f_norm(const Fp2s& a) { return Fp2s{f_norm(a.v)}; }
 PS_INL Fp2s fp_canon(const Fp2s& a) { return Fp2s{fp_canon(a.v)}; }
-// (a0 + a1 u)(b0 + b1 u): even lane a0 b0 - a1 b1, odd lane a0 b1 + a1 b0, as X1*Y1 + X2*Y2.
+// (a0 + a1 u)(b0 + b1 u): even lane a0 b0 - a1 b1, odd lane a1 b0 + a0 b1 -- on both lanes
+//     mine(a) * b0 + cross(a) * b1,   cross(a) = -a1 on the even lane, a0 on the odd one,
+// with b0, b1 broadcast inside the pair: three DPP moves and one xor-add per limb, no per-lane selects.
 // Needs class(a)*class(b) <= 4.
 PS_INL Fp2s f_mul(const Fp2s& a, const Fp2s& b) {
-    const bool odd = pair_lane() != 0;
-    Fp ao = pair_swap(a.v), bo = pair_swap(b.v);
-    Fp x1, x2;
-#pragma unroll
-    for (int i = 0; i < FP_L; i++) {
-        x1.l[i] = odd ? ao.l[i] : a.v.l[i];
-        x2.l[i] = odd ? a.v.l[i] : -ao.l[i];
-    }
-    return Fp2s{f_mul2add(x1, b.v, x2, bo)};
+    return Fp2s{f_mul2add(a.v, pair_bcast0(b.v), pair_cross(a.v), pair_bcast1(b.v))};
 }
 // (a0 + a1)(a0 - a1) on the even lane, 2 a0 a1 on the odd lane
 PS_INL Fp2s f_sqr(const Fp2s& a) {
@@ -1013,18 +1031,8 @@ PS_INL Fp2s f_sqr(const Fp2s& a) {
 // a*b - c*d in Fp2, four real products per lane under one reduction.  Operands are brought to limb class ~1
 // first (two of them arrive as differences in the mixed addition), which keeps the column sums inside 64 bits.
 PS_INL Fp2s f_mul2sub(const Fp2s& a, const Fp2s& b, const Fp2s& c, const Fp2s& d) {
-    const bool odd = pair_lane() != 0;
     const Fp an = f_norm(a.v), bn = f_norm(b.v), cn = f_norm(c.v), dn = f_norm(d.v);
-    const Fp ao = pair_swap(an), bo = pair_swap(bn), co = pair_swap(cn), dp = pair_swap(dn);
-    Fp x1, x2, y1, y2;  // (x1, x2) as in f_mul for a; (y1, y2) the same for c, negated
-#pragma unroll
-    for (int i = 0; i < FP_L; i++) {
-        x1.l[i] = odd ? ao.l[i] : an.l[i];
-        x2.l[i] = odd ? an.l[i] : -ao.l[i];
-        y1.l[i] = odd ? -co.l[i] : -cn.l[i];
-        y2.l[i] = odd ? -cn.l[i] : co.l[i];
-    }
-    return Fp2s{f_mul4add(x1, bn, x2, bo, y1, dn, y2, dp)};
+    return Fp2s{f_mul2add2sub(an, pair_bcast0(bn), pair_cross(an), pair_bcast1(bn), cn, pair_bcast0(dn), pair_cross(cn), pair_bcast1(dn))};
 }
 PS_INL bool f_is_zero(const Fp2s& a) {
     i32 z = f_is_zero(a.v) ? 1 : 0;

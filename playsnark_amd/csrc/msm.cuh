@@ -664,31 +664,41 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const char* __restrict__ 
     u32 bend = offs[g + 1];
     u32 run_start = start;
     Xyzz<KF> acc = xyzz_identity<KF>();
-    u32 e = sorted[start];
-    u32 e1 = start + 1 < end ? sorted[start + 1] : e;  // entries run two ahead of the additions, points one ahead
-    Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
-    for (u32 p = start; p < end; p++) {
-        Affine<KF> nxt = pt;
-        u32 e2 = e1;
-        if (PREFETCH) {
+    if (PREFETCH) {
+        u32 e = sorted[start];
+        u32 e1 = start + 1 < end ? sorted[start + 1] : e;  // entries run two ahead of the additions, points one ahead
+        Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
+        for (u32 p = start; p < end; p++) {
+            Affine<KF> nxt = pt;
+            u32 e2 = e1;
             if (p + 1 < end) nxt = ld_entry_point<KF>(points, e1, idx_mask, w_stride, pstride);
             if (p + 2 < end) e2 = sorted[p + 2];
-        }
-        if (p >= bend) {
-            flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
-            acc = xyzz_identity<KF>();
-            run_start = p;
-            do { g++; bend = offs[g + 1]; } while (bend <= p);
-        }
-        if (!affine_is_identity<KF>(pt)) {
-            if (e >> 31) pt.y = f_neg(pt.y);
-            xyzz_madd<KF>(acc, pt.x, pt.y);
-        }
-        if (PREFETCH) {
+            if (p >= bend) {
+                flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
+                acc = xyzz_identity<KF>();
+                run_start = p;
+                do { g++; bend = offs[g + 1]; } while (bend <= p);
+            }
+            if (!affine_is_identity<KF>(pt)) {
+                if (e >> 31) pt.y = f_neg(pt.y);
+                xyzz_madd<KF>(acc, pt.x, pt.y);
+            }
             pt = nxt; e = e1; e1 = e2;
-        } else if (p + 1 < end) {
-            e = sorted[p + 1];
-            pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
+        }
+    } else {
+        for (u32 p = start; p < end; p++) {
+            if (p >= bend) {
+                flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
+                acc = xyzz_identity<KF>();
+                run_start = p;
+                do { g++; bend = offs[g + 1]; } while (bend <= p);
+            }
+            const u32 e = sorted[p];
+            Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
+            if (!affine_is_identity<KF>(pt)) {
+                if (e >> 31) pt.y = f_neg(pt.y);
+                xyzz_madd<KF>(acc, pt.x, pt.y);
+            }
         }
     }
     flush_run<KF>(acc, g, run_start, end, start, t, offs, buckets, parts);

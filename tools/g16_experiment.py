@@ -1,0 +1,20 @@
+import sys, time, os, random
+sys.path.insert(0, os.getcwd())
+import bench
+from playsnark_amd import api
+ctx = api.Context(0)
+if os.environ.get("NOTAB"): ctx.set_tables(False)
+n = 1 << 20
+nvars, L, Rm, O, sol = bench.synthetic_r1cs(n)
+q = api.QAP.from_csr(ctx, nvars, nvars - 3, L, Rm, O)
+rnd = random.Random(1)
+fr = lambda: rnd.randrange(1 << 20, bench.R_MOD)
+dsol = api.Poly.upload(ctx, sol)
+tr, vk = api.NewGroth16TrustedSetup(q, fr(), fr(), fr(), fr(), fr())
+r, s = fr(), fr()
+api.Groth16Prove(tr, q, dsol, r, s)
+api.Groth16Prove(tr, q, dsol, r, s)
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); api.Groth16Prove(tr, q, dsol, r, s); ts.append((time.perf_counter() - t0) * 1e3)
+print(os.environ.get("TAG", ""), "groth16 ms", [round(t, 2) for t in ts], {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()})
