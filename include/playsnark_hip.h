@@ -139,6 +139,13 @@ int ps_msm_multi(ps_ctx* ctx, const ps_points* const* points, size_t k, const ps
 int ps_point_convert(int group, int in_fmt, int out_fmt, const uint8_t* in, uint8_t* out);
 /* Sum of k affine points (the per-GPU partial sums of a sharded MSM, after the RCCL gather). */
 int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* out);
+/* sum_i scalars[i] * points[i] for a handful of points (k <= 64) on the host: the fixed-point terms of a proof
+ * (r Delta + Alpha ...) and the weighting of partial sums computed elsewhere.  Affine in, affine out. */
+int ps_points_lincomb(int group, const uint8_t* pts, const uint8_t* scalars_be32, size_t k, uint8_t* out);
+/* One sum over index-range shards held by several devices of THIS process: shard d is summed on ctxs[d] (the devices
+ * work side by side), the partial sums are folded on the host.  The in-process form of the sharded MSM of SURVEY 8e
+ * (a cgo caller cannot wrap a function call in one process per GPU). */
+int ps_msm_multi_device(ps_ctx* const* ctxs, const ps_points* const* pts, const ps_scalars* const* scalars, size_t ndev, uint8_t* out);
 /* Tuning / introspection of the last MSM on this context. */
 typedef struct {
     int window_bits;   /* c */
@@ -175,6 +182,11 @@ void ps_qap_free(ps_qap* q);
 int ps_qap_quotient(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, ps_scalars** A, ps_scalars** B,
                     ps_scalars** C, ps_scalars** h);
 
+/* computeAggregatePoly (qap.go:164-175) for ONE of the three polynomials: which = 0 left (A), 1 right (B), 2 out (C);
+ * n coefficients.  No divisibility test (that needs all three: ps_qap_quotient).  The three parts of the quotient --
+ * A, B and h through the h-only route -- are independent, so three GPUs can compute them side by side. */
+int ps_qap_interpolate(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, int which, ps_scalars** out);
+
 /* Poly.Mul (algebra.go:92-105): out = a * b, len(a)+len(b)-1 coefficients (NTT product). */
 int ps_poly_mul(ps_ctx* ctx, const ps_scalars* a, const ps_scalars* b, ps_scalars** out);
 
@@ -201,6 +213,21 @@ int ps_groth16_prove(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, cons
 int ps_groth16_prove_shard(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, const ps_scalars* sol,
                            const uint8_t r_be32[32], const uint8_t s_be32[32], int rank, int world, uint8_t A_part[96],
                            uint8_t B_part[192], uint8_t C_part[96]);
+
+/* Groth16Prove over the devices of one process, every device holding only ITS index range of the CRS arrays: device d
+ * of ndev holds Xi[range(n)], Xi2[range(n)], NioLP[range(nbIO)], XiT[range(n-1)] with range = the d-th of ndev
+ * contiguous parts whose sizes differ by at most one (PS_ERR_LENGTH otherwise); the fixed points are read from dev[0].pk.
+ * Each device has its own context, its own ps_qap of the circuit and its own copy of the solution.  With three or more
+ * devices the parts of the quotient (A, B, h) are computed side by side on devices 0, 1, 2.  Same proof bytes as
+ * ps_groth16_prove. */
+typedef struct {
+    ps_ctx* ctx;
+    const ps_qap* qap;
+    const ps_scalars* sol;
+    ps_groth16_pk pk; /* rank-local arrays */
+} ps_groth16_device;
+int ps_groth16_prove_multi(const ps_groth16_device* dev, size_t ndev, const uint8_t r_be32[32], const uint8_t s_be32[32],
+                           uint8_t A[96], uint8_t B[192], uint8_t C[96]);
 
 typedef struct { /* PHGR13EvalKey (pinochio.go:37-62); ws is G2, every other array is G1 */
     const ps_points *vs, *ws, *ys, *vas, *was, *yas, *gsi, *vbs, *wbs, *ybs;

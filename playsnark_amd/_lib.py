@@ -27,7 +27,8 @@ SYMBOLS = [
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
-    "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_poly_mul",
+    "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_qap_interpolate", "ps_poly_mul",
+    "ps_points_lincomb", "ps_msm_multi_device", "ps_groth16_prove_multi",
     "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_groth16_prove_shard", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
 ]
 
@@ -48,6 +49,10 @@ class Groth16Pk(C.Structure):
     _fields_ = [("alpha", C.c_uint8 * 96), ("beta", C.c_uint8 * 96), ("delta", C.c_uint8 * 96),
                 ("beta2", C.c_uint8 * 192), ("delta2", C.c_uint8 * 192),
                 ("xi", C.c_void_p), ("xi2", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p)]
+
+
+class Groth16Device(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("qap", C.c_void_p), ("sol", C.c_void_p), ("pk", Groth16Pk)]
 
 
 class Groth16Toxic(C.Structure):
@@ -151,6 +156,10 @@ def _load():
     lib.ps_qap_free.restype = None
     lib.ps_qap_quotient.argtypes = [vp, vp, vp, pp, pp, pp, pp]
     lib.ps_poly_mul.argtypes = [vp, vp, vp, pp]
+    lib.ps_qap_interpolate.argtypes = [vp, vp, vp, i, pp]
+    lib.ps_points_lincomb.argtypes = [i, C.c_char_p, C.c_char_p, sz, C.c_char_p]
+    lib.ps_msm_multi_device.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.c_char_p]
+    lib.ps_groth16_prove_multi.argtypes = [C.POINTER(Groth16Device), sz, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.ps_groth16_prove.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.c_char_p, C.c_char_p]
     lib.ps_groth16_prove_shard.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, i, i, C.c_char_p,

@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import PS_G1, PS_G2, lib
 
 G1, G2 = PS_G1, PS_G2
+R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # the scalar field: encodings only, no arithmetic here
 FMT_AFFINE, FMT_COMPRESSED = _lib.PS_FMT_AFFINE, _lib.PS_FMT_COMPRESSED
 _WIRE = {PS_G1: 96, PS_G2: 192}
 
@@ -318,6 +319,24 @@ def point_convert(group: int, raw: bytes, in_fmt: int, out_fmt: int) -> bytes:
     return out.raw
 
 
+def points_lincomb(group: int, points: bytes, scalars: Sequence[int]) -> bytes:
+    """sum_i scalars[i] * points[i] for a handful of affine points, on the host (ps_points_lincomb)."""
+    out = C.create_string_buffer(_WIRE[group])
+    _check(lib.ps_points_lincomb(group, points, b"".join(_be32(k % R_ORDER) for k in scalars), len(scalars), out))
+    return out.raw
+
+
+def msm_multi_device(ctxs: Sequence[Context], shards: Sequence[Points], scalars: Sequence["Poly"]) -> bytes:
+    """One sum whose index-range shards live on several devices of this process (ps_msm_multi_device)."""
+    k = len(ctxs)
+    ca = (C.c_void_p * k)(*[c._h for c in ctxs])
+    pa = (C.c_void_p * k)(*[p._h for p in shards])
+    sa = (C.c_void_p * k)(*[s._h for s in scalars])
+    out = C.create_string_buffer(_WIRE[shards[0].group])
+    _check(lib.ps_msm_multi_device(ca, pa, sa, k, out))
+    return out.raw
+
+
 def points_sum(group: int, raw: bytes) -> bytes:
     """Sum of affine points: folds the per-GPU partial sums after the RCCL gather."""
     out = C.create_string_buffer(_WIRE[group])
@@ -405,6 +424,12 @@ class QAP:
         _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, *[C.byref(h) for h in hs]))
         return tuple(Poly(self.ctx, h) for h in hs)
 
+    def interpolate(self, sol: Poly, which: int) -> Poly:
+        """One of the three aggregate polynomials of computeAggregatePoly (qap.go:164-175): 0 left, 1 right, 2 out."""
+        h = C.c_void_p()
+        _check(lib.ps_qap_interpolate(self.ctx._h, self._h, sol._h, which, C.byref(h)))
+        return Poly(self.ctx, h)
+
     def computeAB(self, sol: Poly):
         """(left, right, h): the Groth16 route -- A and B as coefficient vectors, h = floor(A*B / z); C is never
         interpolated (what Groth16Prove needs, groth16.go:146-185)."""
@@ -478,6 +503,20 @@ def Groth16Prove(tr: Groth16Setup, q: QAP, sol: Poly, r: int, s: int) -> Groth16
     Cc = C.create_string_buffer(96)
     pk = tr._struct()
     _check(lib.ps_groth16_prove(q.ctx._h, C.byref(pk), q._h, sol._h, _be32(r), _be32(s), A, B, Cc))
+    return Groth16Proof(r, s, A.raw, B.raw, Cc.raw)
+
+
+def Groth16ProveMulti(devices: Sequence[tuple], r: int, s: int) -> Groth16Proof:
+    """Groth16Prove over several devices of this process, each holding only its index range of the CRS arrays
+    (ps_groth16_prove_multi).  devices[d] = (Groth16Setup with the d-th ranges, QAP on that device, solution on that device)."""
+    arr = (_lib.Groth16Device * len(devices))()
+    keep = []
+    for d, (tr, q, sol) in enumerate(devices):
+        pk = tr._struct()
+        keep.append(pk)
+        arr[d].ctx, arr[d].qap, arr[d].sol, arr[d].pk = q.ctx._h, q._h, sol._h, pk
+    A, B, Cc = C.create_string_buffer(96), C.create_string_buffer(192), C.create_string_buffer(96)
+    _check(lib.ps_groth16_prove_multi(arr, len(devices), _be32(r), _be32(s), A, B, Cc))
     return Groth16Proof(r, s, A.raw, B.raw, Cc.raw)
 
 

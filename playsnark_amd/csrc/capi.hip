@@ -91,7 +91,7 @@ struct ps_ctx {
     PendingMsm q[PS_MSM_QUEUE];
     int q_head = 0, q_len = 0;
     bool pending = false;            // q_len > 0
-    ps_ctx *pipe = nullptr, *pipe2 = nullptr;
+    ps_ctx *pipe = nullptr, *pipe2 = nullptr, *pipe3 = nullptr;
     hipEvent_t ev_fork = nullptr;
     ps_ctx* last_chain = nullptr;    // workspace of the sum launched last (its ev_acc_local = accumulation done)
     ps_ctx* last_timed = nullptr;
@@ -231,6 +231,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (c->aux) ps_ctx_destroy(c->aux);
     if (c->pipe) ps_ctx_destroy(c->pipe);
     if (c->pipe2) ps_ctx_destroy(c->pipe2);
+    if (c->pipe3) ps_ctx_destroy(c->pipe3);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_multi) if (e) (void)hipEventDestroy(e);
@@ -891,13 +892,16 @@ static void write_identity(int group, uint8_t* out) {  // zero.Clone(), algebra.
     out[0] = 0x40;
 }
 
-// k sums over one scalar vector.  The sort runs on w0's stream; the point passes alternate between the
-// workspaces w0 and w1 (w1 may equal w0 when k == 1), accumulation i+1 chained behind accumulation i
-// so that it runs beside the fix-up and reduction of sum i.  Events live on `c`.
-static int msm_multi_launch(ps_ctx* c, ps_ctx* w0, ps_ctx* w1, const ps_points* const* pts, size_t k, const ps_scalars* sc,
-                            const MsmPlan& pl) {
+// k sums over one scalar vector.  The sort runs on ring[0]'s stream; the point passes rotate over the workspaces of
+// `ring` (entries may coincide when k is small), accumulation i+1 chained behind accumulation i so that it runs beside
+// the fix-up and reduction of sum i.  Four workspaces: a tail that shares the chip with the following accumulations is
+// starved of CUs and may outlast two of them (measured: 8 ms for a G2 tail under three G1 accumulations), and the sum
+// that reuses its buffers must not wait for it.  Events live on `c`.
+constexpr int PS_MULTI_RING = 4;
+static int msm_multi_sort(ps_ctx* c, ps_ctx* const* ring, const ps_scalars* sc, const MsmPlan& pl, bool fork) {
     int rc;
-    if (w0 != c) {  // inputs prepared on the context stream are visible to the worker streams
+    ps_ctx* w0 = ring[0];
+    if (w0 != c && fork) {  // inputs prepared on the context stream are visible to the worker streams
         if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(hipStreamWaitEvent(w0->stream, c->ev_fork, 0));
@@ -906,21 +910,45 @@ static int msm_multi_launch(ps_ctx* c, ps_ctx* w0, ps_ctx* w1, const ps_points* 
     w0->ev_valid = false;
     if (!c->ev_sorted) HIP_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->ev_sorted, w0->stream));
-    if (w1 != w0) HIP_TRY(hipStreamWaitEvent(w1->stream, c->ev_sorted, 0));
+    for (int j = 1; j < PS_MULTI_RING; j++) {
+        bool seen = false;
+        for (int i = 0; i < j; i++) seen = seen || ring[i] == ring[j];
+        if (!seen) HIP_TRY(hipStreamWaitEvent(ring[j]->stream, c->ev_sorted, 0));
+    }
+    return PS_OK;
+}
+// first_wait: a point pass launched before this call that the first accumulation is chained behind
+static int msm_multi_points(ps_ctx* c, ps_ctx* const* ring, const ps_points* const* pts, size_t k, const ps_scalars* sc,
+                            const MsmPlan& pl, hipEvent_t first_wait) {
+    ps_ctx* w0 = ring[0];
     for (size_t i = 0; i < k; i++) {
         if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
         if (!c->ev_acc[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming));
-        ps_ctx* wc = (i & 1) ? w1 : w0;
-        hipEvent_t wait = i ? c->ev_acc[i - 1] : nullptr;
-        rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i])
-                                    : msm_points_t<Fp2>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i]);
+        ps_ctx* wc = ring[i % PS_MULTI_RING];
+        hipEvent_t wait = i ? c->ev_acc[i - 1] : first_wait;
+        int rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i])
+                                        : msm_points_t<Fp2>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i]);
         if (rc) {
-            (void)ps_ctx_sync(w0);
-            (void)ps_ctx_sync(w1);
+            for (int j = 0; j < PS_MULTI_RING; j++) (void)ps_ctx_sync(ring[j]);
             return rc;
         }
         HIP_TRY(hipEventRecord(c->ev_multi[i], wc->tail));
     }
+    return PS_OK;
+}
+// the workspaces of a multi-sum on context c: `self` puts the context itself first (ps_msm_multi), otherwise only workers
+static int msm_multi_ring(ps_ctx* c, bool self, size_t k, ps_ctx** ring) {
+    ps_ctx** slots[4] = {&c->aux, &c->pipe, &c->pipe2, &c->pipe3};
+    int have = 0;
+    if (self) ring[have++] = c;
+    for (int j = 0; have < PS_MULTI_RING && (size_t)have < std::max<size_t>(k, 1); j++) {
+        if (!*slots[j]) {
+            int rc = ps_ctx_create(c->device, slots[j]);
+            if (rc) return rc;
+        }
+        ring[have++] = *slots[j];
+    }
+    for (int j = have; j < PS_MULTI_RING; j++) ring[j] = ring[j % have];
     return PS_OK;
 }
 
@@ -963,9 +991,11 @@ extern "C" int ps_msm_multi(ps_ctx* c, const ps_points* const* pts, size_t k, co
     HIP_TRY(hipSetDevice(c->device));
     MsmPlan pl;
     if ((rc = msm_plan_checked(c, pts, k, sc->n, sc->max_bits, &pl))) return rc;
-    if (k > 1 && !c->aux && (rc = ps_ctx_create(c->device, &c->aux))) return rc;
     if (c->aux && c->aux->pending) return fail(PS_ERR_ARG, "ps_msm_multi: the auxiliary context is busy");
-    if ((rc = msm_multi_launch(c, c, k > 1 ? c->aux : c, pts, k, sc, pl))) return rc;
+    ps_ctx* ring[PS_MULTI_RING];
+    if ((rc = msm_multi_ring(c, true, k, ring))) return rc;
+    if ((rc = msm_multi_sort(c, ring, sc, pl, true))) return rc;
+    if ((rc = msm_multi_points(c, ring, pts, k, sc, pl, nullptr))) return rc;
     return msm_multi_finish(c, c, pts, k, pl, out);
 }
 

@@ -75,8 +75,11 @@ struct NttFuse {
     u64 top = 0;                  // REV_PAD / REV_TAKE: index that maps to 0
 };
 
+// __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Two 512-thread workgroups
+// per CU need 4 waves per SIMD, i.e. at most 128 VGPRs; with "2" the inverse pass took 139 and ran one workgroup per CU
+// (measured: no difference in the quotient's time either way -- the passes are bound by their instruction count).
 template <bool INV>
-__global__ void __launch_bounds__(512, 2) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+__global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
                                                   const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);

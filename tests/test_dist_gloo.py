@@ -111,6 +111,57 @@ print("rank", rank, "ok")
 
 import pytest  # noqa: E402
 
+LOCAL_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from oracle import pyref as pr, restate as rs
+from playsnark_amd import api
+from playsnark_amd.dist import ShardedGroth16Local, shard_range
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ctx = api.Context(0)  # rehearsal: every rank on the one GPU of the box
+rng = pr.SplitMix64(1234)
+c, sol = rs.synthetic_circuit(77)
+c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
+tox = [rng.fr() for _ in range(5)]
+r, s = rng.fr(), rng.fr()
+tr = rs.groth16_setup(c, *tox)
+want = rs.groth16_prove(tr, c, sol, r, s)
+def part(raw, total, nb, group):
+    first, cnt = shard_range(total, rank, world)
+    return api.Points.upload(ctx, group, raw[first * nb:(first + cnt) * nb])  # this rank uploads ITS range only
+n, nn = c.nbGates, c.nbIO
+key = api.Groth16Setup(tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2, part(tr.Xi, n, 96, api.G1), part(tr.Xi2, n, 192, api.G2),
+                       part(tr.NioLP, nn, 96, api.G1), part(tr.XiT, n - 1, 96, api.G1))
+q = api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
+got = ShardedGroth16Local(ctx, dist, world, rank).prove(key, q, api.Poly.upload(ctx, sol), r, s)
+assert (got.A, got.B, got.C) == (want.A, want.B, want.C), rank
+bad = list(sol); bad[7] = (bad[7] + 1) %% pr.R
+try:
+    ShardedGroth16Local(ctx, dist, world, rank).prove(key, q, api.Poly.upload(ctx, bad), r, s)
+    raise SystemExit("no apocalypse on rank %%d" %% rank)
+except api.Apocalypse:
+    pass
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+@pytest.mark.gpu
+def test_groth16_three_ranks_with_local_keys_and_split_quotient(tmp_path):
+    """Three processes (gloo, all on GPU 0): each uploads only its index ranges of the CRS; rank 0 interpolates A, rank 1 B,
+    rank 2 computes h, three broadcasts hand them round; the folded proof equals the oracle's; a bad witness raises
+    Apocalypse on every rank."""
+    script = tmp_path / "worker.py"
+    script.write_text(LOCAL_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert res.stdout.count("ok") == 3
+
 
 @pytest.mark.gpu
 def test_sharded_provers_two_ranks_on_one_gpu(tmp_path):

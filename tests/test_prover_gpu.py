@@ -385,3 +385,109 @@ def test_sharded_groth16_partials_fold_to_the_proof(ps_api, ctx, co, pr, world):
         assert (folded.A, folded.B, folded.C) == (whole.A, whole.B, whole.C)
     with pytest.raises(ps_api.PlaysnarkError):
         ShardedGroth16(ctx, None, 2, 0).partials(tr, q, sol_dev, r, s, rank=2)
+
+
+def _local_groth16_key(ps_api, ctx, tr, n, nn, rank, world):
+    """The d-th index ranges of an oracle-made Groth16 setup, uploaded on their own (a rank-local CRS)."""
+    from playsnark_amd.dist import shard_range
+
+    def part(raw, total, nb, group):
+        first, cnt = shard_range(total, rank, world)
+        return ps_api.Points.upload(ctx, group, raw[first * nb:(first + cnt) * nb])
+
+    return ps_api.Groth16Setup(tr.Alpha, tr.Beta, tr.Delta, tr.Beta2, tr.Delta2, part(tr.Xi, n, 96, ps_api.G1),
+                               part(tr.Xi2, n, 192, ps_api.G2), part(tr.NioLP, nn, 96, ps_api.G1), part(tr.XiT, n - 1, 96, ps_api.G1))
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 5])
+def test_groth16_prove_over_rank_local_keys(ps_api, ctx, co, pr, ndev):
+    """Rank-local CRS (every rank / device holds only its index ranges): (i) ps_groth16_prove_multi, the in-process
+    multi-device entry -- here `ndev` contexts on the one GPU, each with its own QAP, solution and local arrays; with three or
+    more the quotient's parts A, B, h come from different contexts --; (ii) ShardedGroth16Local, the one-process-per-GPU form,
+    with simulated ranks.  Both give the bytes of the oracle's (and the unsharded) proof; wrong ranges are refused."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedGroth16, ShardedGroth16Local
+
+    rng = pr.SplitMix64(SEED + 6000 + ndev)
+    c, sol = rs.synthetic_circuit(53)
+    c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
+    tox = [rng.fr() for _ in range(5)]
+    r, s = rng.fr(), rng.fr()
+    tr = rs.groth16_setup(c, *tox)
+    want = rs.groth16_prove(tr, c, sol, r, s)
+    n, nn = c.nbGates, c.nbIO
+    ctxs = [ctx] + [ps_api.Context(0) for _ in range(ndev - 1)]
+    devices = []
+    for d, cx in enumerate(ctxs):
+        q = _upload_circuit(ps_api, cx, c)
+        devices.append((_local_groth16_key(ps_api, cx, tr, n, nn, d, ndev), q, ps_api.Poly.upload(cx, sol)))
+    proof = ps_api.Groth16ProveMulti(devices, r, s)
+    assert (proof.A, proof.B, proof.C) == (want.A, want.B, want.C)
+    # the same through the per-rank class, ranks simulated one after the other on their own contexts
+    parts = [ShardedGroth16Local(cx, None, ndev, d).partials(devices[d][0], devices[d][1], devices[d][2], r, s) for d, cx in enumerate(ctxs)]
+    folded = ShardedGroth16.fold(parts, r, s)
+    assert (folded.A, folded.B, folded.C) == (want.A, want.B, want.C)
+    if ndev > 1:  # a rank that holds someone else's range is told so (BlindEval would panic on the lengths, algebra.go:350-352)
+        wrong = [devices[0]] + [(devices[0][0], devices[d][1], devices[d][2]) for d in range(1, ndev)]
+        with pytest.raises(ps_api.LengthMismatch):
+            ps_api.Groth16ProveMulti(wrong, r, s)
+        with pytest.raises(ps_api.LengthMismatch):
+            ShardedGroth16Local(ctxs[1], None, ndev, 1).partials(_local_groth16_key(ps_api, ctxs[1], tr, n, nn, 1, ndev + 1),
+                                                                  devices[1][1], devices[1][2], r, s)
+    bad = list(sol)
+    bad[5] = (bad[5] + 1) % pr.R
+    with pytest.raises(ps_api.Apocalypse):
+        ps_api.Groth16ProveMulti([(k, q, ps_api.Poly.upload(q.ctx, bad)) for k, q, _ in devices], r, s)
+    for cx in ctxs[1:]:
+        cx.close()
+
+
+def test_msm_over_shards_on_several_contexts(ps_api, ctx, co, pr):
+    """ps_msm_multi_device: index-range shards on different contexts (devices) of one process, summed side by side."""
+    from playsnark_amd.dist import shard_range
+
+    rng = pr.SplitMix64(SEED + 6100)
+    n, ndev = 1000, 3
+    sc = [rng.fr() for _ in range(n)]
+    ctxs = [ctx, ps_api.Context(0), ps_api.Context(0)]
+    for gid, og in ((ps_api.G1, co.G1), (ps_api.G2, co.G2)):
+        raw = og.gen_points(rng.fr(), rng.fr(), n)
+        shards, scs = [], []
+        for d, cx in enumerate(ctxs):
+            first, cnt = shard_range(n, d, ndev)
+            shards.append(ps_api.Points.upload(cx, gid, raw[first * og.nb:(first + cnt) * og.nb]))
+            scs.append(ps_api.Poly.upload(cx, sc[first:first + cnt]))
+        assert ps_api.msm_multi_device(ctxs, shards, scs) == og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+    assert ps_api.points_lincomb(ps_api.G1, co.G1.to_b(co.G1.mul(5)) + co.G1.to_b(co.G1.mul(7)), [3, pr.R - 2]) == co.G1.to_b(co.G1.mul(1))
+    for cx in ctxs[1:]:
+        cx.close()
+
+
+def test_sharded_phgr13_over_rank_local_keys(ps_api, ctx, co, pr):
+    """ShardedPHGR13(local=True): the evaluation key of a rank holds only its index ranges."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedPHGR13, shard_range
+
+    rng = pr.SplitMix64(SEED + 6200)
+    c, sol = rs.synthetic_circuit(41)
+    c = rs.SparseR1CS(c.nbVars, c.nbVars - 3, c.left, c.right, c.out)
+    setup = rs.phgr13_setup(c, *[rng.fr() for _ in range(8)])
+    want = rs.phgr13_prove(setup.EK, c, sol, fast=True)
+    q = _upload_circuit(ps_api, ctx, c)
+    sol_dev = ps_api.Poly.upload(ctx, sol)
+    world = 3
+    parts = []
+    for g in range(world):
+        fields = {}
+        for f in ps_api.PHGR13EvalKey.FIELDS:
+            raw, nb = getattr(setup.EK, f), (192 if f == "ws" else 96)
+            first, cnt = shard_range(len(raw) // nb, g, world)
+            fields[f] = ps_api.Points.upload(ctx, ps_api.G2 if f == "ws" else ps_api.G1, raw[first * nb:(first + cnt) * nb])
+        sh = ShardedPHGR13(ctx, None, world, g, local=True)
+        parts.append(sh.partials(ps_api.PHGR13EvalKey(**fields), q, sol_dev))
+        if g == 1:
+            with pytest.raises(ps_api.LengthMismatch):
+                ShardedPHGR13(ctx, None, world + 1, g, local=True).partials(ps_api.PHGR13EvalKey(**fields), q, sol_dev)
+    folded = ShardedPHGR13.fold(parts)
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(folded, f) == getattr(want, f), f
