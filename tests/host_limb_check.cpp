@@ -1,0 +1,307 @@
+// host_limb_check.cpp -- machine check of the lazy-limb contract of playsnark_amd/csrc/field.cuh / curve.cuh and of the
+// host-side pairing arithmetic (pairing_math.inc), compiled FOR THE HOST with
+//     g++ -std=c++17 -O1 -fsanitize=address,undefined -fno-sanitize-recover=all -pthread
+// so that every signed 64-bit column sum, every shift and every array access of the product's field code runs under
+// UBSan / ASan (GPU sanitizers are not available on the pool; the arithmetic is the same source on both sides).
+//
+// The contract (field.cuh): limbs are 28-bit, signed and lazy; "class c" means |limb| < c * 2^28.
+//   f_mul(a, b)                 needs class(a) class(b) <= 8
+//   f_mul2sub / f_mul2add       need  class(a) class(b) + class(c) class(d) <= 8
+//   f_mul2add2sub               needs the four class products to add up to <= 8
+//   fr_mul(a, b)                needs class(a) class(b) <= 11
+// Each is driven with WORST-CASE operands of every admissible class combination (all limbs at +-(c 2^28 - 1), equal
+// and alternating signs -- the extreme column sums) and with random lazy operands, and compared, after canonical
+// reduction, with the same product on reduced operands; results must land in the documented output range.  Then the
+// group law (madd / add / dbl chains, limb class of every stored coordinate tracked), the NTT butterfly sequences
+// exactly as k_ntt_pass issues them (forward: no reduction for 32 stages; inverse: 16 unscaled stages), and the
+// Miller loop + final exponentiation (bilinearity).  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <vector>
+
+#include "../playsnark_amd/csrc/curve.cuh"
+
+using namespace ps;
+
+// what pairing_math.inc expects from msm.cuh / capi.hip
+template <class F> static bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }
+#include "../playsnark_amd/csrc/pairing_math.inc"
+
+static unsigned long long rng_state = 0x706c6179736e6172ull;
+static unsigned long long rnd() {  // splitmix64
+    unsigned long long z = (rng_state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static int failures = 0;
+#define CHECK(cond, ...)                                                            \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            failures++;                                                             \
+            std::fprintf(stderr, "FAIL %s:%d: %s  ", __FILE__, __LINE__, #cond);    \
+            std::fprintf(stderr, __VA_ARGS__);                                      \
+            std::fprintf(stderr, "\n");                                             \
+        }                                                                           \
+    } while (0)
+
+static int limb_class(const Fp& a) {  // smallest c with |l[i]| < c * 2^28 for all i
+    long long m = 0;
+    for (int i = 0; i < FP_L; i++) { long long v = a.l[i] < 0 ? -(long long)a.l[i] : a.l[i]; if (v > m) m = v; }
+    return (int)(m >> 28) + 1;
+}
+static int limb_class(const Fr& a) {
+    long long m = 0;
+    for (int i = 0; i < FR_L; i++) { long long v = a.l[i] < 0 ? -(long long)a.l[i] : a.l[i]; if (v > m) m = v; }
+    return (int)(m >> 28) + 1;
+}
+// The contract has two parts: the limb class, and |value| <= 16 p.  p has 381 bits, so the top limb (bits 364..) of an
+// admissible value is at most 16 * p_top; the thirteen limbs below it are pushed to the edge of the class.
+static const long long TOP_SPAN = 15ll * fp_mod28(FP_L - 1);
+static Fp worst(int cls, int pattern) {  // pattern 0: all +, 1: all -, 2: alternating, 3: random signs
+    Fp r;
+    for (int i = 0; i < FP_L; i++) {
+        i32 v = i == FP_L - 1 ? (i32)TOP_SPAN : (i32)(((long long)cls << 28) - 1);
+        bool neg = pattern == 1 || (pattern == 2 && (i & 1)) || (pattern == 3 && (rnd() & 1));
+        r.l[i] = neg ? -v : v;
+    }
+    return r;
+}
+static Fp random_lazy(int cls) {
+    Fp r;
+    for (int i = 0; i < FP_L; i++) {
+        long long span = i == FP_L - 1 ? TOP_SPAN : ((long long)cls << 28) - 1;
+        r.l[i] = (i32)((long long)(rnd() % (unsigned long long)(2 * span + 1)) - span);
+    }
+    return r;
+}
+static Fp reduced(const Fp& a) { return f_mul(a, fp_one()); }  // same residue, value in (-p/8, 9p/8); class(a) <= 8
+static bool same_residue(const Fp& a, const Fp& b) { return fp_all_zero(f_sub(fp_canon(reduced(a)), fp_canon(reduced(b)))); }
+static void check_mul_output(const Fp& r, const char* what) {
+    for (int i = 0; i < FP_L - 1; i++) CHECK(r.l[i] >= 0 && r.l[i] < (1 << 28), "%s: limb %d = %d outside [0, 2^28)", what, i, r.l[i]);
+    CHECK(r.l[FP_L - 1] > -(1 << 25) && r.l[FP_L - 1] < (1 << 27), "%s: top limb %d", what, r.l[FP_L - 1]);
+}
+
+static void test_fp_products() {
+    int combos = 0;
+    for (int ca = 1; ca <= 8; ca++)
+        for (int cb = 1; ca * cb <= 8; cb++)
+            for (int pa = 0; pa < 4; pa++)
+                for (int pb = 0; pb < 4; pb++) {
+                    Fp a = worst(ca, pa), b = worst(cb, pb);
+                    Fp r = f_mul(a, b);
+                    check_mul_output(r, "f_mul");
+                    CHECK(same_residue(r, f_mul(reduced(a), reduced(b))), "f_mul classes %d x %d patterns %d %d", ca, cb, pa, pb);
+                    combos++;
+                }
+    for (int it = 0; it < 2000; it++) {
+        int ca = 1 + (int)(rnd() % 8), cb = 1 + (int)(rnd() % (8 / ca));
+        Fp a = random_lazy(ca), b = random_lazy(cb);
+        Fp r = f_mul(a, b);
+        check_mul_output(r, "f_mul random");
+        CHECK(same_residue(r, f_mul(reduced(a), reduced(b))), "f_mul random classes %d x %d", ca, cb);
+        if (ca * ca <= 8) CHECK(same_residue(f_sqr(a), f_mul(reduced(a), reduced(a))), "f_sqr class %d", ca);
+    }
+    // two and four products under one reduction
+    for (int c1 = 1; c1 <= 7; c1++)
+        for (int c2 = 1; c1 + c2 <= 8; c2++)
+            for (int pat = 0; pat < 4; pat++) {
+                // class products c1 and c2: (c1 x 1) and (1 x c2), and the square-ish splits where they exist
+                Fp a = worst(c1, pat), b = worst(1, (pat + 1) & 3), c = worst(1, (pat + 2) & 3), d = worst(c2, (pat + 3) & 3);
+                Fp want_sub = f_sub(f_mul(reduced(a), reduced(b)), f_mul(reduced(c), reduced(d)));
+                Fp want_add = f_add(f_mul(reduced(a), reduced(b)), f_mul(reduced(c), reduced(d)));
+                Fp rs = f_mul2sub(a, b, c, d), ra = f_mul2add(a, b, c, d);
+                check_mul_output(rs, "f_mul2sub");
+                check_mul_output(ra, "f_mul2add");
+                CHECK(same_residue(rs, want_sub), "f_mul2sub class products %d + %d", c1, c2);
+                CHECK(same_residue(ra, want_add), "f_mul2add class products %d + %d", c1, c2);
+                combos++;
+            }
+    for (int it = 0; it < 500; it++) {  // four products: class products 2 + 2 + 2 + 2 = 8 and random splits
+        int cls[4] = {2, 2, 2, 2};
+        if (it & 1) { cls[0] = 1 + (int)(rnd() % 5); cls[1] = 1 + (int)(rnd() % (6 - cls[0])); cls[2] = 1; cls[3] = 8 - cls[0] - cls[1] - 1; if (cls[3] < 1) cls[3] = 1; }
+        Fp x[8];
+        for (int k = 0; k < 4; k++) { x[2 * k] = it < 64 ? worst(cls[k], it & 3) : random_lazy(cls[k]); x[2 * k + 1] = it < 64 ? worst(1, (it >> 2) & 3) : random_lazy(1); }
+        Fp r = f_mul2add2sub(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+        check_mul_output(r, "f_mul2add2sub");
+        Fp want = f_sub(f_add(f_mul(reduced(x[0]), reduced(x[1])), f_mul(reduced(x[2]), reduced(x[3]))),
+                        f_add(f_mul(reduced(x[4]), reduced(x[5])), f_mul(reduced(x[6]), reduced(x[7]))));
+        CHECK(same_residue(r, want), "f_mul2add2sub classes %d %d %d %d", cls[0], cls[1], cls[2], cls[3]);
+    }
+    // f_norm: value unchanged, class back to ~1; f_is_zero on multiples of p inside its contract
+    for (int it = 0; it < 500; it++) {
+        Fp a = random_lazy(1 + (int)(rnd() % 8));
+        Fp nrm = f_norm(a);
+        CHECK(limb_class(nrm) <= 2, "f_norm left class %d", limb_class(nrm));
+        CHECK(same_residue(a, nrm), "f_norm changed the value");
+    }
+    Fp kp = fp_zero();
+    for (int k = -7; k <= 7; k++) {  // k p limb by limb stays inside class 8 for |k| <= 7
+        Fp v;
+        for (int i = 0; i < FP_L; i++) v.l[i] = (i32)((long long)k * fp_mod28(i));
+        CHECK(f_is_zero(v), "f_is_zero(%d p)", k);
+        v.l[0] += 1;
+        CHECK(!f_is_zero(v), "f_is_zero(%d p + 1)", k);
+    }
+    (void)kp;
+    std::printf("fp products: %d worst-case class combinations and 3000 random cases ok\n", combos);
+}
+
+// Fr: |value| < 64 r (the storage discipline of field.cuh) bounds the top limb; a class above 7 does not fit an i32 limb
+static Fr fr_worst(int cls, int pattern) {
+    Fr r;
+    for (int i = 0; i < FR_L; i++) {
+        i32 v = i == FR_L - 1 ? (i32)(63ll * fr_mod28(FR_L - 1)) : (i32)(((long long)cls << 28) - 1);
+        bool neg = pattern == 1 || (pattern == 2 && (i & 1)) || (pattern == 3 && (rnd() & 1));
+        r.l[i] = neg ? -v : v;
+    }
+    return r;
+}
+static Fr fr_random_canon() {
+    u32 w[8];
+    for (int i = 0; i < 8; i++) w[i] = (u32)rnd();
+    w[7] &= 0x3fffffffu;  // < 2^254 < r
+    return fr_to_mont(fr_from_words8(w));
+}
+static bool fr_same(const Fr& a, const Fr& b) {
+    Fr d = fr_canon(fr_reduce(fr_sub(fr_reduce(a), fr_reduce(b))));
+    for (int i = 0; i < FR_L; i++) if (d.l[i]) return false;
+    return true;
+}
+static void test_fr_and_butterflies() {
+    for (int ca = 1; ca <= 7; ca++)
+        for (int cb = 1; cb <= 7 && ca * cb <= 11; cb++)
+            for (int pat = 0; pat < 16; pat++) {
+                Fr a = fr_worst(ca, pat & 3), b = fr_worst(cb, pat >> 2);
+                Fr r = fr_mul(a, b);
+                for (int i = 0; i < FR_L - 1; i++) CHECK(r.l[i] >= 0 && r.l[i] < (1 << 28), "fr_mul limb %d = %d", i, r.l[i]);
+                CHECK(fr_same(r, fr_mul(fr_reduce(a), fr_reduce(b))), "fr_mul classes %d x %d", ca, cb);
+            }
+    // Forward (Cooley-Tukey) butterflies as k_ntt_pass issues them: a' = norm(a + w b), b' = norm(a - w b), no reduction
+    // between stages; 32 stages is the deepest transform the field supports.  Checked against the same recurrence with a
+    // canonical reduction after every stage.
+    const int N = 64;
+    std::vector<Fr> lazy(N), ref(N), tw(N);
+    for (int i = 0; i < N; i++) { lazy[i] = ref[i] = fr_random_canon(); tw[i] = fr_random_canon(); }
+    int worst_class = 0;
+    for (int stage = 0; stage < 32; stage++) {
+        const int half = 1 << (stage % 6);
+        for (int i = 0; i < N; i++) {
+            if (i & half) continue;
+            Fr wb = fr_mul(lazy[i | half], tw[(i + stage) % N]);
+            Fr a = lazy[i];
+            lazy[i] = fr_norm(fr_add(a, wb));
+            lazy[i | half] = fr_norm(fr_sub(a, wb));
+            Fr wr = fr_mul(ref[i | half], tw[(i + stage) % N]);
+            Fr ar = ref[i];
+            ref[i] = fr_canon(fr_reduce(fr_add(ar, wr)));
+            ref[i | half] = fr_canon(fr_reduce(fr_sub(ar, wr)));
+        }
+        for (int i = 0; i < N; i++) { int c = limb_class(lazy[i]); if (c > worst_class) worst_class = c; }
+    }
+    for (int i = 0; i < N; i++) CHECK(fr_same(lazy[i], ref[i]), "forward butterflies diverged at %d", i);
+    CHECK(worst_class <= 3, "forward butterflies reached limb class %d", worst_class);
+    // Inverse (Gentleman-Sande): a' = norm(a + b), b' = norm(a - b) * w; the all-sums path doubles per stage and ntt_run
+    // divides the factor out after at most 16 stages.
+    for (int i = 0; i < N; i++) lazy[i] = ref[i] = fr_random_canon();
+    for (int stage = 0; stage < 16; stage++) {
+        const int half = 1 << (stage % 6);
+        for (int i = 0; i < N; i++) {
+            if (i & half) continue;
+            Fr a = lazy[i], b = lazy[i | half];
+            lazy[i] = fr_norm(fr_add(a, b));
+            lazy[i | half] = fr_mul(fr_norm(fr_sub(a, b)), tw[(i + stage) % N]);
+            Fr ar = ref[i], br = ref[i | half];
+            ref[i] = fr_canon(fr_reduce(fr_add(ar, br)));
+            ref[i | half] = fr_canon(fr_reduce(fr_mul(fr_canon(fr_reduce(fr_sub(ar, br))), tw[(i + stage) % N])));
+        }
+    }
+    Fr sc = fr_random_canon();
+    for (int i = 0; i < N; i++) CHECK(fr_same(fr_mul(lazy[i], sc), fr_mul(ref[i], sc)), "inverse butterflies diverged at %d", i);
+    std::printf("fr products and NTT butterfly sequences ok (forward: limb class <= %d after 32 stages)\n", worst_class);
+}
+
+template <class F> static int coord_class(const F& a);
+template <> int coord_class<Fp>(const Fp& a) { return limb_class(a); }
+template <> int coord_class<Fp2>(const Fp2& a) { int x = limb_class(a.c0), y = limb_class(a.c1); return x > y ? x : y; }
+static Affine<Fp> gen_of(const Fp*) {
+    Affine<Fp> g;
+    constexpr i32 x[FP_L] = PS_G1_GEN28_X; constexpr i32 y[FP_L] = PS_G1_GEN28_Y;
+    for (int i = 0; i < FP_L; i++) { g.x.l[i] = x[i]; g.y.l[i] = y[i]; }
+    return g;
+}
+static Affine<Fp2> gen_of(const Fp2*) {
+    Affine<Fp2> g;
+    constexpr i32 x0[FP_L] = PS_G2_GEN28_X0; constexpr i32 x1[FP_L] = PS_G2_GEN28_X1;
+    constexpr i32 y0[FP_L] = PS_G2_GEN28_Y0; constexpr i32 y1[FP_L] = PS_G2_GEN28_Y1;
+    for (int i = 0; i < FP_L; i++) { g.x.c0.l[i] = x0[i]; g.x.c1.l[i] = x1[i]; g.y.c0.l[i] = y0[i]; g.y.c1.l[i] = y1[i]; }
+    return g;
+}
+template <class F>
+static Affine<F> small_multiple(u32 k) {
+    Affine<F> g = gen_of((const F*)0), r;
+    Xyzz<F> t = xyzz_mul_small<F>(xyzz_from_affine<F>(g.x, g.y), k);
+    if (!xyzz_to_affine<F>(t, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
+    return r;
+}
+template <class F>
+static void test_group_law(const char* name) {
+    // a bucket's life: a long chain of mixed additions (with repeats and P, -P pairs), partial sums added together,
+    // doublings -- the stored coordinates must stay at limb class <= 2 and the result must not depend on the order
+    const int K = 40;
+    std::vector<Affine<F>> pts;
+    std::vector<u32> ks;
+    for (int i = 0; i < K; i++) { u32 k = 1 + (u32)(rnd() % 5000); if (i % 7 == 3) k = ks[i - 1]; ks.push_back(k); pts.push_back(small_multiple<F>(k)); }
+    unsigned long long total = 0;
+    Xyzz<F> acc = xyzz_identity<F>(), left = xyzz_identity<F>(), right = xyzz_identity<F>();
+    int worst_cls = 0;
+    for (int i = 0; i < K; i++) {
+        xyzz_madd<F>(acc, pts[i].x, pts[i].y);
+        xyzz_madd<F>(i < K / 2 ? left : right, pts[i].x, pts[i].y);
+        total += ks[i];
+        int c = std::max(std::max(coord_class<F>(acc.x), coord_class<F>(acc.y)), std::max(coord_class<F>(acc.zz), coord_class<F>(acc.zzz)));
+        if (c > worst_cls) worst_cls = c;
+    }
+    xyzz_add<F>(left, right);
+    F ax, ay, bx, by, cx, cy;
+    CHECK(xyzz_to_affine<F>(acc, ax, ay) && xyzz_to_affine<F>(left, bx, by), "%s: chain ended in the identity", name);
+    CHECK(fp_all_zero(f_sub(ax, bx)) && fp_all_zero(f_sub(ay, by)), "%s: (sum of halves) != serial sum", name);
+    Affine<F> g = gen_of((const F*)0);
+    u32 kw[8] = {(u32)total, (u32)(total >> 32), 0, 0, 0, 0, 0, 0};
+    Xyzz<F> direct = xyzz_mul_scalar<F>(xyzz_from_affine<F>(g.x, g.y), kw);
+    CHECK(xyzz_to_affine<F>(direct, cx, cy) && fp_all_zero(f_sub(ax, cx)) && fp_all_zero(f_sub(ay, cy)), "%s: chain != [sum k] G", name);
+    CHECK(worst_cls <= 2, "%s: stored coordinates reached limb class %d", name, worst_cls);
+    // P + (-P) and P + P through the mixed adder
+    Xyzz<F> t = xyzz_from_affine<F>(pts[0].x, pts[0].y);
+    xyzz_madd<F>(t, pts[0].x, f_neg(pts[0].y));
+    CHECK(xyzz_is_identity(t), "%s: P + (-P) is not the identity", name);
+    t = xyzz_from_affine<F>(pts[0].x, pts[0].y);
+    xyzz_madd<F>(t, pts[0].x, pts[0].y);
+    Xyzz<F> d = xyzz_dbl<F>(xyzz_from_affine<F>(pts[0].x, pts[0].y));
+    F dx, dy, ex, ey;
+    CHECK(xyzz_to_affine<F>(t, dx, dy) && xyzz_to_affine<F>(d, ex, ey) && fp_all_zero(f_sub(dx, ex)) && fp_all_zero(f_sub(dy, ey)), "%s: P + P != 2P", name);
+    std::printf("%s group law ok (stored coordinates at limb class <= %d over %d mixed additions)\n", name, worst_cls, K);
+}
+
+static void test_pairing() {
+    // e(aP, bQ) == e(abP, Q) and != e((ab + 1)P, Q): the Miller loop carries its point without a multiplication between
+    // steps (canon_wide), the tower products nest lazy values three levels deep
+    Affine<Fp> P = small_multiple<Fp>(6), P210 = small_multiple<Fp>(210), P211 = small_multiple<Fp>(211);
+    Affine<Fp2> Q35 = small_multiple<Fp2>(35), Q1 = small_multiple<Fp2>(1);
+    CHECK(pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P210), Q1}}), "e(6P, 35Q) != e(210P, Q)");
+    CHECK(!pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P211), Q1}}), "e(6P, 35Q) == e(211P, Q)");
+    std::printf("pairing bilinearity ok\n");
+}
+
+int main() {
+    test_fp_products();
+    test_fr_and_butterflies();
+    test_group_law<Fp>("G1");
+    test_group_law<Fp2>("G2");
+    test_pairing();
+    if (failures) { std::fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
+    std::printf("host_limb_check ok\n");
+    return 0;
+}
