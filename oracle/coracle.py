@@ -254,3 +254,19 @@ def quotient_from_values(yA, yB, yC):
         raise ArithmeticError("apocalypse")
     assert rc == 0, rc
     return tuple(unpack_fr(b.raw) for b in bufs) + (unpack_fr(h.raw)[: n - 1],)
+
+
+def fast_quotient_bytes(yA: bytes, yB: bytes, yC: bytes, n: int):
+    """B1-h: (A, B, C, h) as big-endian byte strings by the quasi-linear CPU algorithm (n up to 2^20)."""
+    bufs = [_buf(32 * n) for _ in range(3)]
+    h = _buf(32 * max(n - 1, 1))
+    rc = lib().or_fast_quotient(yA, yB, yC, C.c_size_t(n), *bufs, h)
+    if rc == ERR_NOT_DIVISIBLE:
+        raise ArithmeticError("apocalypse")
+    assert rc == 0, rc
+    return tuple(b.raw for b in bufs) + (h.raw[: 32 * (n - 1)],)
+
+
+def fast_quotient(yA, yB, yC):
+    n = len(yA)
+    return tuple(unpack_fr(b) for b in fast_quotient_bytes(pack_fr(yA), pack_fr(yB), pack_fr(yC), n))

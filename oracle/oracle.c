@@ -10,6 +10,7 @@
 #include "oracle.h"
 
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -923,4 +924,214 @@ double or_now(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+
+/* ------------------------------------------------------------------------------------ */
+/* B1-h: a FAST CPU statement of the same polynomials -- the aggregate     */
+/* polynomials A, B, C of computeAggregatePoly (qap.go:164-175) as interpolants of L.s, R.s, O.s    */
+/* on {1..n}, and h = (A*B - C)/z of QAP.Quotient (qap.go:151-162) -- for sizes where the literal   */
+/* O(n^3) restatement above cannot run (n = 2^16 .. 2^20).  Quasi-linear: NTT products over Fr,     */
+/* values -> Newton coefficients by one convolution with (-1)^j / j!, Newton -> monomial by a       */
+/* recursive product tree, exact division by z through a power-series inverse of rev(z).           */
+/* Scalar code, 64-bit Montgomery limbs, recursion instead of the GPU's level-wise passes; pinned   */
+/* against or_quotient_from_values (the literal algorithm) in tests/test_oracle_golden.py.          */
+/* ------------------------------------------------------------------------------------ */
+static fr_t FQ_ROOT[33]; /* FQ_ROOT[k]: primitive 2^k-th root of unity */
+static pthread_once_t fq_once = PTHREAD_ONCE_INIT;
+static void fq_init(void) {
+    /* 7 generates Fr^*; w = 7^((r-1)/2^32) has order 2^32 (checked: w^(2^31) = -1) */
+    fr_t g, w, minus1;
+    fr_set_u64(&g, 7);
+    u64 e[4];
+    memcpy(e, R_LIMBS, sizeof e);
+    e[0] -= 1; /* r - 1, low limb is ...00000001 */
+    /* shift right by 32 */
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 32) | (i + 1 < 4 ? e[i + 1] << 32 : 0);
+    mont_pow(w.l, g.l, e, 4, &FR);
+    FQ_ROOT[32] = w;
+    for (int k = 31; k >= 0; k--) fr_mul(&FQ_ROOT[k], &FQ_ROOT[k + 1], &FQ_ROOT[k + 1]);
+    fr_set_i64(&minus1, -1);
+    if (memcmp(&FQ_ROOT[1], &minus1, sizeof(fr_t)) != 0 || memcmp(&FQ_ROOT[0], FR.r1, sizeof(fr_t)) != 0) {
+        fprintf(stderr, "oracle: 7 is not a generator of Fr^* ?\n");
+        abort();
+    }
+}
+static int fq_log2_ceil(size_t v) { int l = 0; while (((size_t)1 << l) < v) l++; return l; }
+
+/* in-place radix-2 NTT of 2^lg points (natural order in and out); inverse includes the 1/n scaling */
+static void fq_ntt(fr_t* a, int lg, int inverse) {
+    const size_t n = (size_t)1 << lg;
+    for (size_t i = 1, j = 0; i < n; i++) { /* bit reversal */
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { fr_t t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (int s = 1; s <= lg; s++) {
+        const size_t half = (size_t)1 << (s - 1);
+        fr_t wlen = FQ_ROOT[s];
+        if (inverse) fr_inv(&wlen, &wlen);
+        fr_t* tw = (fr_t*)malloc(sizeof(fr_t) * half);
+        tw[0] = *(fr_t*)FR.r1;
+        for (size_t k = 1; k < half; k++) fr_mul(&tw[k], &tw[k - 1], &wlen);
+        for (size_t i = 0; i < n; i += 2 * half)
+            for (size_t k = 0; k < half; k++) {
+                fr_t u = a[i + k], v;
+                fr_mul(&v, &a[i + k + half], &tw[k]);
+                fr_add(&a[i + k], &u, &v);
+                fr_sub(&a[i + k + half], &u, &v);
+            }
+        free(tw);
+    }
+    if (inverse) {
+        fr_t ninv;
+        fr_set_u64(&ninv, (u64)n);
+        fr_inv(&ninv, &ninv);
+        for (size_t i = 0; i < n; i++) fr_mul(&a[i], &a[i], &ninv);
+    }
+}
+/* out[0..nout) = (a*b)[0..nout); out may alias neither input */
+static void fq_mul(fr_t* out, size_t nout, const fr_t* a, size_t na, const fr_t* b, size_t nb) {
+    if (na == 0 || nb == 0) { memset(out, 0, sizeof(fr_t) * nout); return; }
+    const size_t full = na + nb - 1;
+    if (na < 32 || nb < 32) {
+        fr_t* t = (fr_t*)malloc(sizeof(fr_t) * full);
+        poly_mul_fr(t, a, na, b, nb);
+        for (size_t i = 0; i < nout; i++) { if (i < full) out[i] = t[i]; else memset(&out[i], 0, sizeof(fr_t)); }
+        free(t);
+        return;
+    }
+    const int lg = fq_log2_ceil(full);
+    const size_t S = (size_t)1 << lg;
+    fr_t* fa = (fr_t*)calloc(S, sizeof(fr_t));
+    fr_t* fb = (fr_t*)calloc(S, sizeof(fr_t));
+    memcpy(fa, a, sizeof(fr_t) * na);
+    memcpy(fb, b, sizeof(fr_t) * nb);
+    fq_ntt(fa, lg, 0);
+    fq_ntt(fb, lg, 0);
+    for (size_t i = 0; i < S; i++) fr_mul(&fa[i], &fa[i], &fb[i]);
+    fq_ntt(fa, lg, 1);
+    for (size_t i = 0; i < nout; i++) { if (i < full) out[i] = fa[i]; else memset(&out[i], 0, sizeof(fr_t)); }
+    free(fa); free(fb);
+}
+/* Newton coefficients d[lo..hi) on the nodes 1, 2, ..: returns N(x) = sum_{k in [lo,hi)} d_k prod_{i=lo+1..k}(x - i)
+ * (hi-lo coefficients) in `nout`, and Z(x) = prod_{i=lo+1..hi}(x - i) (hi-lo+1 coefficients, monic) in `zout` */
+static void fq_newton_to_monomial(const fr_t* d, size_t lo, size_t hi, fr_t* nout, fr_t* zout) {
+    const size_t len = hi - lo;
+    if (len == 1) {
+        nout[0] = d[lo];
+        fr_set_i64(&zout[0], -(int64_t)(lo + 1));
+        zout[1] = *(fr_t*)FR.r1;
+        return;
+    }
+    const size_t mid = lo + len / 2, ll = mid - lo, lr = hi - mid;
+    fr_t* nl = (fr_t*)malloc(sizeof(fr_t) * ll);
+    fr_t* zl = (fr_t*)malloc(sizeof(fr_t) * (ll + 1));
+    fr_t* nr = (fr_t*)malloc(sizeof(fr_t) * lr);
+    fr_t* zr = (fr_t*)malloc(sizeof(fr_t) * (lr + 1));
+    fq_newton_to_monomial(d, lo, mid, nl, zl);
+    fq_newton_to_monomial(d, mid, hi, nr, zr);
+    /* N = N_left + Z_left * N_right  (degree < len) ; Z = Z_left * Z_right */
+    fr_t* t = (fr_t*)malloc(sizeof(fr_t) * (len + 1));
+    fq_mul(t, len, zl, ll + 1, nr, lr);
+    for (size_t i = 0; i < len; i++) { nout[i] = t[i]; if (i < ll) fr_add(&nout[i], &nout[i], &nl[i]); }
+    fq_mul(zout, len + 1, zl, ll + 1, zr, lr + 1);
+    free(nl); free(zl); free(nr); free(zr); free(t);
+}
+/* monomial coefficients (n of them) of the interpolant of ys on the nodes 1..n; z (n+1 coefficients) as a by-product */
+static void fq_interpolate(const fr_t* ys, size_t n, const fr_t* invfact, fr_t* out, fr_t* z) {
+    /* divided differences on equally spaced nodes: d_k = sum_j (y_j / j!) * (-1)^(k-j) / (k-j)!,  j = 0..k (y_j = f(j+1)) */
+    fr_t* u = (fr_t*)malloc(sizeof(fr_t) * n);
+    fr_t* v = (fr_t*)malloc(sizeof(fr_t) * n);
+    for (size_t j = 0; j < n; j++) {
+        fr_mul(&u[j], &ys[j], &invfact[j]);
+        v[j] = invfact[j];
+        if (j & 1) fr_neg(&v[j], &v[j]);
+    }
+    fr_t* d = (fr_t*)malloc(sizeof(fr_t) * n);
+    fq_mul(d, n, u, n, v, n);
+    fr_t* zz = (fr_t*)malloc(sizeof(fr_t) * (n + 1));
+    fq_newton_to_monomial(d, 0, n, out, zz);
+    if (z) memcpy(z, zz, sizeof(fr_t) * (n + 1));
+    free(u); free(v); free(d); free(zz);
+}
+typedef struct { const fr_t* ys; size_t n; const fr_t* invfact; fr_t* out; fr_t* z; } fq_job;
+static void* fq_job_run(void* p) {
+    fq_job* j = (fq_job*)p;
+    fq_interpolate(j->ys, j->n, j->invfact, j->out, j->z);
+    return NULL;
+}
+/* g = f^-1 mod x^m for f[0] != 0 (Newton iteration g <- g (2 - f g)) */
+static void fq_series_inverse(const fr_t* f, size_t nf, size_t m, fr_t* g) {
+    memset(g, 0, sizeof(fr_t) * m);
+    fr_inv(&g[0], &f[0]);
+    fr_t two;
+    fr_set_u64(&two, 2);
+    fr_t* t = (fr_t*)malloc(sizeof(fr_t) * (m + 1));
+    fr_t* g2 = (fr_t*)malloc(sizeof(fr_t) * (m + 1));
+    for (size_t cur = 1; cur < m;) {
+        const size_t nxt = 2 * cur < m ? 2 * cur : m;
+        fq_mul(t, nxt, f, nf < nxt ? nf : nxt, g, cur);
+        for (size_t i = 0; i < nxt; i++) fr_neg(&t[i], &t[i]);
+        fr_add(&t[0], &t[0], &two);
+        fq_mul(g2, nxt, g, cur, t, nxt);
+        memcpy(g, g2, sizeof(fr_t) * nxt);
+        cur = nxt;
+    }
+    free(t); free(g2);
+}
+int or_fast_quotient(const uint8_t* yA, const uint8_t* yB, const uint8_t* yC, size_t n, uint8_t* A, uint8_t* B, uint8_t* C, uint8_t* h) {
+    ensure_init();
+    pthread_once(&fq_once, fq_init);
+    if (n < 2) return OR_ERR_LENGTH;
+    fr_t *ya = poly_load(yA, n), *yb = poly_load(yB, n), *yc = poly_load(yC, n);
+    int rc = OR_OK;
+    for (size_t j = 0; j < n && rc == OR_OK; j++) { /* z | A*B - C  <=>  the gate equation holds at every root of z */
+        fr_t t;
+        fr_mul(&t, &ya[j], &yb[j]);
+        if (memcmp(&t, &yc[j], sizeof t) != 0) rc = OR_ERR_NOT_DIVISIBLE;
+    }
+    fr_t* invfact = (fr_t*)malloc(sizeof(fr_t) * n);
+    {
+        fr_t f = *(fr_t*)FR.r1, k;
+        for (size_t j = 1; j < n; j++) { fr_set_u64(&k, (u64)j); fr_mul(&f, &f, &k); }
+        fr_inv(&f, &f); /* 1/(n-1)! */
+        for (size_t j = n; j-- > 0;) { invfact[j] = f; if (j) { fr_set_u64(&k, (u64)j); fr_mul(&f, &f, &k); } }
+    }
+    fr_t *pa = (fr_t*)malloc(sizeof(fr_t) * n), *pb = (fr_t*)malloc(sizeof(fr_t) * n), *pc = (fr_t*)malloc(sizeof(fr_t) * n);
+    fr_t* z = (fr_t*)malloc(sizeof(fr_t) * (n + 1));
+    { /* the three interpolations are independent: one thread each */
+        fq_job jobs[3] = {{ya, n, invfact, pa, z}, {yb, n, invfact, pb, NULL}, {yc, n, invfact, pc, NULL}};
+        pthread_t th[2];
+        pthread_create(&th[0], NULL, fq_job_run, &jobs[1]);
+        pthread_create(&th[1], NULL, fq_job_run, &jobs[2]);
+        fq_job_run(&jobs[0]);
+        pthread_join(th[0], NULL);
+        pthread_join(th[1], NULL);
+    }
+    poly_store(A, pa, n); poly_store(B, pb, n); poly_store(C, pc, n);
+    if (rc == OR_OK) {
+        /* P = A*B - C, degree <= 2n-2; h = P / z: reversed, rev(h) = rev(P) * rev(z)^-1 mod x^(n-1) */
+        const size_t np = 2 * n - 1, m = n - 1;
+        fr_t* P = (fr_t*)malloc(sizeof(fr_t) * np);
+        fq_mul(P, np, pa, n, pb, n);
+        for (size_t i = 0; i < n; i++) fr_sub(&P[i], &P[i], &pc[i]);
+        fr_t *rz = (fr_t*)malloc(sizeof(fr_t) * (n + 1)), *rp = (fr_t*)malloc(sizeof(fr_t) * m), *g = (fr_t*)malloc(sizeof(fr_t) * m);
+        for (size_t i = 0; i <= n; i++) rz[i] = z[n - i];
+        for (size_t i = 0; i < m; i++) rp[i] = P[np - 1 - i];
+        fq_series_inverse(rz, n + 1, m, g);
+        fr_t* rh = (fr_t*)malloc(sizeof(fr_t) * m);
+        fq_mul(rh, m, rp, m, g, m);
+        fr_t* hh = (fr_t*)malloc(sizeof(fr_t) * m);
+        for (size_t i = 0; i < m; i++) hh[i] = rh[m - 1 - i];
+        /* the division must be exact: h * z == P */
+        fr_t* chk = (fr_t*)malloc(sizeof(fr_t) * np);
+        fq_mul(chk, np, hh, m, z, n + 1);
+        if (memcmp(chk, P, sizeof(fr_t) * np) != 0) rc = OR_ERR_NOT_DIVISIBLE;
+        poly_store(h, hh, m);
+        free(P); free(rz); free(rp); free(g); free(rh); free(hh); free(chk);
+    }
+    free(ya); free(yb); free(yc); free(invfact); free(pa); free(pb); free(pc); free(z);
+    return rc;
 }

@@ -99,6 +99,10 @@ int or_quotient_from_values(const uint8_t* yA, const uint8_t* yB, const uint8_t*
                             uint8_t* A, uint8_t* B, uint8_t* C, uint8_t* h);
 
 /* CPU timing helper for bench.py's cpu_baseline leg: seconds for one call of the named op */
+/* B1-h: the same polynomials by a quasi-linear CPU algorithm (NTT products, Newton basis,
+ * product tree, series division) for n up to 2^20.  A, B, C: n coefficients; h: n-1.  OR_ERR_NOT_DIVISIBLE <=> "apocalypse". */
+int or_fast_quotient(const uint8_t* yA, const uint8_t* yB, const uint8_t* yC, size_t n, uint8_t* A, uint8_t* B, uint8_t* C, uint8_t* h);
+
 double or_now(void);
 
 #ifdef __cplusplus

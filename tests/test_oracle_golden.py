@@ -15,7 +15,10 @@ def test_public_constants(pr):
     # ZCash/IETF compressed generator encodings (public known answers)
     assert pr.g1_compress(pr.G1.gen).hex() == (
         "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
-    assert pr.g2_compress(pr.G2.gen).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61a")
+    # the full 96 bytes: x_c1 || x_c0 with the flag bits on the first byte -- this also pins the coordinate ORDER of G2
+    assert pr.g2_compress(pr.G2.gen).hex() == (
+        "93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+        "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
 
 
 def test_curve_known_answers(co, pr):
@@ -113,3 +116,24 @@ def test_phgr13_toy_fixture(co, pr):
     pp = rs.phgr13_prove(st.EK, c, [pr.fr(v) for v in wit])
     for k, v in g["proof"].items():
         assert getattr(pp, k).hex() == v, k
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 7, 33, 64, 100, 257])
+def test_fast_quotient_is_the_literal_algorithm(co, pr, n):
+    """B1-h: the quasi-linear CPU oracle for A, B, C, h (NTT products, Newton basis, product tree, series
+    division) against the literal restatement of computeAggregatePoly + Mul + Sub + Div2 (qap.go:151-175) -- which is what
+    pins it; the GPU tests then use it at sizes the literal algorithm cannot reach (2^16)."""
+    from oracle import restate as rs
+
+    if n >= 4:
+        c, sol = rs.synthetic_circuit(n)
+        dot = lambda rows: [sum(v * sol[j] for j, v in row) % pr.R for row in rows]
+        yA, yB, yC = dot(c.left), dot(c.right), dot(c.out)
+    else:
+        rng = pr.SplitMix64(n)
+        yA, yB = [rng.fr() for _ in range(n)], [rng.fr() for _ in range(n)]
+        yC = [a * b % pr.R for a, b in zip(yA, yB)]
+    assert tuple(map(list, co.fast_quotient(yA, yB, yC))) == tuple(map(list, co.quotient_from_values(yA, yB, yC)))
+    yC[n // 2] = (yC[n // 2] + 1) % pr.R
+    with pytest.raises(ArithmeticError):
+        co.fast_quotient(yA, yB, yC)

@@ -491,3 +491,21 @@ def test_sharded_phgr13_over_rank_local_keys(ps_api, ctx, co, pr):
     folded = ShardedPHGR13.fold(parts)
     for f in ps_api.PHGR13Proof.FIELDS:
         assert getattr(folded, f) == getattr(want, f), f
+
+
+def test_aggregate_polynomials_and_h_byte_exact_at_2pow16(ps_api, ctx, co, pr):
+    """A, B, C and h at n = 2^16 -- far beyond the literal O(n^3) restatement -- byte for byte against the oracle's fast CPU
+    algorithm (or_fast_quotient, itself pinned to the literal one at small n), both routes of the GPU quotient."""
+    from oracle import restate as rs
+
+    n = 1 << 16
+    c, sol = rs.synthetic_circuit(n)
+    dot = lambda rows: [sum(v * sol[j] for j, v in row) % pr.R for row in rows]
+    want = co.fast_quotient_bytes(co.pack_fr(dot(c.left)), co.pack_fr(dot(c.right)), co.pack_fr(dot(c.out)), n)
+    q = _upload_circuit(ps_api, ctx, c)
+    dsol = ps_api.Poly.upload(ctx, sol)
+    got = tuple(p.download_bytes() for p in q.computeAggregatePoly(dsol))
+    for name, g, w in zip("ABCh", got, want):
+        assert g == w, name
+    assert q.Quotient(dsol).download_bytes() == want[3]      # the h-only route
+    assert q.interpolate(dsol, 1).download_bytes() == want[1]  # one polynomial alone
