@@ -1,3 +1,4 @@
+"""Groth16Prove at 2^20 constraints in a loop (for rocprofv3 timelines / PMC passes / A-B runs)."""
 import sys, time, os, random
 sys.path.insert(0, os.getcwd())
 import bench
@@ -15,6 +16,6 @@ r, s = fr(), fr()
 api.Groth16Prove(tr, q, dsol, r, s)
 api.Groth16Prove(tr, q, dsol, r, s)
 ts = []
-for _ in range(5):
+for _ in range(int(os.environ.get("REPS", "5"))):
     t0 = time.perf_counter(); api.Groth16Prove(tr, q, dsol, r, s); ts.append((time.perf_counter() - t0) * 1e3)
 print(os.environ.get("TAG", ""), "groth16 ms", [round(t, 2) for t in ts], {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()})
