@@ -198,6 +198,16 @@ typedef struct { /* the prover's part of Groth16Setup (groth16.go:30-61) */
     const ps_points* xi2;                   /* n   G2 (declared []G1 at groth16.go:60) */
     const ps_points* nio_lp;                /* n_vars - (n_vars - n_io) ... see `diff` note */
     const ps_points* xi_t;                  /* n-1 G1 */
+    /* Optional (NULL = absent): the same CRS in LAGRANGE form, as ps_groth16_setup also emits it --
+     *   lxi[j-1]  = l_j(x) G1,  lxi2[j-1] = l_j(x) G2         l_j the Lagrange basis of the QAP domain {1..n} (qap.go:42-55)
+     *   lxi_t[k-1] = lambda_k(x) t(x)/delta G1                 lambda_k the Lagrange basis of the nodes n+1..2n-1
+     * With all three present the prover needs no polynomial in coefficient form: A(x) G = sum_j (L.s)_j lxi_j, likewise B,
+     * and h(x) t(x)/delta G = sum_k h(n+k) lxi_t_k -- the interpolations and the division of the quotient (three quarters of
+     * it) disappear, the proof is the same group elements.  A key made by the reference's NewGroth16TrustedSetup has only
+     * the monomial arrays above; then the coefficients are computed as QAP.Quotient does. */
+    const ps_points* lxi;                   /* n   G1 */
+    const ps_points* lxi2;                  /* n   G2 */
+    const ps_points* lxi_t;                 /* n-1 G1 */
 } ps_groth16_pk;
 /* Groth16Prove (groth16.go:122-211).  r, s are inputs (the reference draws them at :148,:158 and
  * keeps them in the proof, :203-206).  diff = n_vars - n_io is used as the first non-IO index
@@ -231,6 +241,9 @@ int ps_groth16_prove_multi(const ps_groth16_device* dev, size_t ndev, const uint
 
 typedef struct { /* PHGR13EvalKey (pinochio.go:37-62); ws is G2, every other array is G1 */
     const ps_points *vs, *ws, *ys, *vas, *was, *yas, *gsi, *vbs, *wbs, *ybs;
+    /* Optional (NULL = absent): lgsi[k-1] = lambda_k(s) G1, the Lagrange form of gsi on the nodes n+1..2n-1 (n-1 points, as
+     * ps_phgr13_setup emits it): hs = sum_k h(n+k) lgsi_k without interpolating h. */
+    const ps_points* lgsi;
 } ps_phgr13_ek;
 typedef struct { /* PHGR13Proof (pinochio.go:180-203) */
     uint8_t vss[96], vass[96], wss[192], wass[96], yss[96], yass[96], hs[96], gz[96];
@@ -251,6 +264,7 @@ typedef struct { /* type Groth16Setup (groth16.go:30-61) without the toxic waste
     uint8_t alpha[96], beta[96], delta[96];        /* G1 */
     uint8_t beta2[192], delta2[192], gamma[192];   /* G2 */
     ps_points *xi, *xi2, *io_lp, *nio_lp, *xi_t;    /* caller frees with ps_points_free */
+    ps_points *lxi, *lxi2, *lxi_t;                  /* the Lagrange form (see ps_groth16_pk); caller frees */
 } ps_groth16_crs;
 /* NewGroth16TrustedSetup (groth16.go:64-101) with the toxic waste supplied by the caller. */
 int ps_groth16_setup(ps_ctx* ctx, const ps_qap* q, const ps_groth16_toxic* tw, ps_groth16_crs* out);
@@ -260,10 +274,11 @@ typedef struct { /* PHGR13Setup (pinochio.go:28-35) without the toxic waste */
     ps_points *gsi, *vs, *ws, *ys, *vas, *was, *yas, *vbs, *wbs, *ybs;                  /* PHGR13EvalKey, pinochio.go:37-62 */
     uint8_t av[192], aw[96], ay[192], gamma[192], bgamma[96], bgamma2[192], yts[192]; /* PHGR13VerifKey, pinochio.go:64-91 */
     ps_points *vk_vs, *vk_ws, *vk_ys; /* vk.vs, vk.ws (G2), vk.ys over ALL variables; vs/ws/ys above are their [diff:] views */
+    ps_points* lgsi;                  /* the Lagrange form of gsi (see ps_phgr13_ek) */
 } ps_phgr13_crs;
 /* NewPHGR13TrustedSetup (pinochio.go:93-176) with the toxic waste supplied by the caller. */
 int ps_phgr13_setup(ps_ctx* ctx, const ps_qap* q, const ps_phgr13_toxic* tw, ps_phgr13_crs* out);
-void ps_phgr13_crs_free(ps_phgr13_crs* crs); /* frees the 13 arrays */
+void ps_phgr13_crs_free(ps_phgr13_crs* crs); /* frees the 14 arrays */
 
 /* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */
 typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */

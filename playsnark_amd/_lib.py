@@ -48,7 +48,8 @@ class Csr(C.Structure):
 class Groth16Pk(C.Structure):
     _fields_ = [("alpha", C.c_uint8 * 96), ("beta", C.c_uint8 * 96), ("delta", C.c_uint8 * 96),
                 ("beta2", C.c_uint8 * 192), ("delta2", C.c_uint8 * 192),
-                ("xi", C.c_void_p), ("xi2", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p)]
+                ("xi", C.c_void_p), ("xi2", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p),
+                ("lxi", C.c_void_p), ("lxi2", C.c_void_p), ("lxi_t", C.c_void_p)]  # the Lagrange form, NULL = absent
 
 
 class Groth16Device(C.Structure):
@@ -62,7 +63,8 @@ class Groth16Toxic(C.Structure):
 class Groth16Crs(C.Structure):
     _fields_ = [("alpha", C.c_uint8 * 96), ("beta", C.c_uint8 * 96), ("delta", C.c_uint8 * 96),
                 ("beta2", C.c_uint8 * 192), ("delta2", C.c_uint8 * 192), ("gamma", C.c_uint8 * 192),
-                ("xi", C.c_void_p), ("xi2", C.c_void_p), ("io_lp", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p)]
+                ("xi", C.c_void_p), ("xi2", C.c_void_p), ("io_lp", C.c_void_p), ("nio_lp", C.c_void_p), ("xi_t", C.c_void_p),
+                ("lxi", C.c_void_p), ("lxi2", C.c_void_p), ("lxi_t", C.c_void_p)]
 
 
 class Groth16Vk(C.Structure):
@@ -77,7 +79,7 @@ class Phgr13Vk(C.Structure):
 
 
 class Phgr13Ek(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("vs", "ws", "ys", "vas", "was", "yas", "gsi", "vbs", "wbs", "ybs")]
+    _fields_ = [(n, C.c_void_p) for n in ("vs", "ws", "ys", "vas", "was", "yas", "gsi", "vbs", "wbs", "ybs", "lgsi")]
 
 
 class Phgr13Toxic(C.Structure):
@@ -88,7 +90,7 @@ class Phgr13Crs(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("gsi", "vs", "ws", "ys", "vas", "was", "yas", "vbs", "wbs", "ybs")] +
                 [("av", C.c_uint8 * 192), ("aw", C.c_uint8 * 96), ("ay", C.c_uint8 * 192), ("gamma", C.c_uint8 * 192),
                  ("bgamma", C.c_uint8 * 96), ("bgamma2", C.c_uint8 * 192), ("yts", C.c_uint8 * 192)] +
-                [(n, C.c_void_p) for n in ("vk_vs", "vk_ws", "vk_ys")])
+                [(n, C.c_void_p) for n in ("vk_vs", "vk_ws", "vk_ys", "lgsi")])
 
 
 class Phgr13Proof(C.Structure):

@@ -460,9 +460,17 @@ class Groth16Setup:
     """The prover's part of type Groth16Setup (groth16.go:30-61)."""
 
     def __init__(self, Alpha: bytes, Beta: bytes, Delta: bytes, Beta2: bytes, Delta2: bytes, Xi: Points,
-                 Xi2: Points, NioLP: Points, XiT: Points):
+                 Xi2: Points, NioLP: Points, XiT: Points, LXi: Optional[Points] = None, LXi2: Optional[Points] = None,
+                 LXiT: Optional[Points] = None):
+        """LXi, LXi2, LXiT: the same CRS in Lagrange form (l_j(x) G1, l_j(x) G2, lambda_k(x) t(x)/delta G1), as the device
+        setup emits it; with all three the prover needs no polynomial in coefficient form (ps_groth16_pk)."""
         self.Alpha, self.Beta, self.Delta, self.Beta2, self.Delta2 = Alpha, Beta, Delta, Beta2, Delta2
         self.Xi, self.Xi2, self.NioLP, self.XiT = Xi, Xi2, NioLP, XiT
+        self.LXi, self.LXi2, self.LXiT = LXi, LXi2, LXiT
+
+    def monomial_only(self) -> "Groth16Setup":
+        """The key as the reference's NewGroth16TrustedSetup makes it: the monomial arrays alone."""
+        return Groth16Setup(self.Alpha, self.Beta, self.Delta, self.Beta2, self.Delta2, self.Xi, self.Xi2, self.NioLP, self.XiT)
 
     def _struct(self):
         pk = _lib.Groth16Pk()
@@ -470,6 +478,8 @@ class Groth16Setup:
                           ("beta2", self.Beta2), ("delta2", self.Delta2)):
             C.memmove(getattr(pk, name), src, len(src))
         pk.xi, pk.xi2, pk.nio_lp, pk.xi_t = self.Xi._h, self.Xi2._h, self.NioLP._h, self.XiT._h
+        if self.LXi is not None and self.LXi2 is not None and self.LXiT is not None:
+            pk.lxi, pk.lxi2, pk.lxi_t = self.LXi._h, self.LXi2._h, self.LXiT._h
         return pk
 
 
@@ -482,9 +492,9 @@ def NewGroth16TrustedSetup(qap: "QAP", alpha: int, beta: int, delta: int, x: int
         C.memmove(getattr(tw, name), _be32(v), 32)
     crs = _lib.Groth16Crs()
     _check(lib.ps_groth16_setup(qap.ctx._h, qap._h, C.byref(tw), C.byref(crs)))
-    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in ("xi", "xi2", "io_lp", "nio_lp", "xi_t")}
+    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in ("xi", "xi2", "io_lp", "nio_lp", "xi_t", "lxi", "lxi2", "lxi_t")}
     tr = Groth16Setup(bytes(crs.alpha), bytes(crs.beta), bytes(crs.delta), bytes(crs.beta2), bytes(crs.delta2),
-                      pts["xi"], pts["xi2"], pts["nio_lp"], pts["xi_t"])
+                      pts["xi"], pts["xi2"], pts["nio_lp"], pts["xi_t"], pts["lxi"], pts["lxi2"], pts["lxi_t"])
     return tr, {"Gamma": bytes(crs.gamma), "IoLP": pts["io_lp"]}
 
 
@@ -528,11 +538,17 @@ class PHGR13EvalKey:
     def __init__(self, **kw):
         for f in self.FIELDS:
             setattr(self, f, kw[f])
+        self.lgsi = kw.get("lgsi")  # optional: gsi in Lagrange form on the nodes n+1..2n-1 (ps_phgr13_ek.lgsi)
+
+    def monomial_only(self) -> "PHGR13EvalKey":
+        return PHGR13EvalKey(**{f: getattr(self, f) for f in self.FIELDS})
 
     def _struct(self):
         ek = _lib.Phgr13Ek()
         for f in self.FIELDS:
             setattr(ek, f, getattr(self, f)._h)
+        if self.lgsi is not None:
+            ek.lgsi = self.lgsi._h
         return ek
 
 
@@ -558,8 +574,8 @@ def NewPHGR13TrustedSetup(qap: "QAP", s: int, av: int, aw: int, ay: int, rv: int
         C.memmove(getattr(tw, name), _be32(v), 32)
     crs = _lib.Phgr13Crs()
     _check(lib.ps_phgr13_setup(qap.ctx._h, qap._h, C.byref(tw), C.byref(crs)))
-    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in PHGR13EvalKey.FIELDS + ("vk_vs", "vk_ws", "vk_ys")}
-    ek = PHGR13EvalKey(**{f: pts[f] for f in PHGR13EvalKey.FIELDS})
+    pts = {f: Points(qap.ctx, C.c_void_p(getattr(crs, f))) for f in PHGR13EvalKey.FIELDS + ("vk_vs", "vk_ws", "vk_ys", "lgsi")}
+    ek = PHGR13EvalKey(lgsi=pts["lgsi"], **{f: pts[f] for f in PHGR13EvalKey.FIELDS})
     vk = PHGR13VerifKey(pts["vk_vs"], pts["vk_ws"], pts["vk_ys"], **{f: bytes(getattr(crs, f)) for f in PHGR13VerifKey.FIXED})
     return ek, vk
 

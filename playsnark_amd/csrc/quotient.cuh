@@ -397,8 +397,11 @@ static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_
 //   h(n+k) = z(n+k) S_A(k) S_B(k) - S_C(k)         k = 1..n-1 (z(n+k) != 0)
 // and h (degree <= n-2) is the interpolant of those n-1 values on the nodes n+1..2n-1: ONE values ->
 // monomial conversion instead of two plus a product and a division.  Same polynomial, bit for bit.
-static inline hipError_t quotient_h_only(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* yA, const Fr* yB,
-                                         const Fr* yC, Fr* h_out) {
+// hv[k-1] = h(n+k), k = 1..n-1, into qt.scratch: three cyclic convolutions and one element-wise kernel.  These values
+// are all a prover needs of h when its key carries the Lagrange-form points of the nodes n+1..2n-1 (ps_groth16_pk.lxi_t,
+// ps_phgr13_ek.lgsi): h(x) G = sum_k h(n+k) lambda_k(x) G, no interpolation at all.
+static inline hipError_t quotient_h_values(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* yA, const Fr* yB,
+                                           const Fr* yC) {
     const u64 n = qt.n, L = 2 * qt.np;
     if (n < 2) return hipSuccess;
     const Fr* ys[3] = {yA, yB, yC};
@@ -410,9 +413,16 @@ static inline hipError_t quotient_h_only(const NttTables& tabs, hipStream_t st, 
         QT_TRY(ntt_run<false>(tabs, st, S[k], L, qt.lognp + 1, f));
         QT_TRY(ntt_run<true>(tabs, st, S[k], L, qt.lognp + 1));
     }
-    Fr* hv = qt.scratch;
-    hipLaunchKernelGGL(k_h_values, dim3(nblk(n - 1)), dim3(256), 0, st, hv, (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2],
+    hipLaunchKernelGGL(k_h_values, dim3(nblk(n - 1)), dim3(256), 0, st, qt.scratch, (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2],
                        (const Fr*)qt.fact2, (const Fr*)qt.invfact, n);
+    return hipGetLastError();
+}
+static inline hipError_t quotient_h_only(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* yA, const Fr* yB,
+                                         const Fr* yC, Fr* h_out) {
+    const u64 n = qt.n;
+    if (n < 2) return hipSuccess;
+    QT_TRY(quotient_h_values(tabs, st, qt, yA, yB, yC));
+    Fr* hv = qt.scratch;
     QT_TRY(interpolate_on_nodes(tabs, st, qt, hv, n - 1, qt.np_h, qt.lognp_h, qt.vhat_h, qt.zhat_h, n));
     return hipMemcpyAsync(h_out, qt.data, sizeof(Fr) * (n - 1), hipMemcpyDeviceToDevice, st);
 }

@@ -213,13 +213,31 @@ def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     assert tr.XiT.download() == want.XiT
     assert tr.NioLP.download() == want.NioLP
     assert vk["IoLP"].download() == want.IoLP
+    # the same CRS in Lagrange form: l_j(x) G on {1..n} in both groups, lambda_k(x) t(x)/delta G on the nodes n+1..2n-1
+    x, delta = tox[3], tox[2]
+    lj, zx = rs.lagrange_at(n, x)
+    lam, _ = rs.lagrange_at(n - 1, (x - n) % pr.R)  # equally spaced nodes: the basis of {n+1..2n-1} at x is that of {1..n-1} at x-n
+    assert tr.LXi.download() == b"".join(co.G1.to_b(co.G1.mul(v)) for v in lj)
+    assert tr.LXi2.download() == b"".join(co.G2.to_b(co.G2.mul(v)) for v in lj)
+    assert tr.LXiT.download() == b"".join(co.G1.to_b(co.G1.mul(v * pr.fr_div(zx, delta) % pr.R)) for v in lam)
     r, s = rng.fr(), rng.fr()
-    proof = ps_api.Groth16Prove(tr, q, ps_api.Poly.upload(ctx, sol), r, s)
+    dsol = ps_api.Poly.upload(ctx, sol)
+    proof = ps_api.Groth16Prove(tr, q, dsol, r, s)  # the Lagrange route: no interpolation, no division
     ref = rs.groth16_prove(want, c, sol, r, s, fast=n > 16)
     assert (proof.A, proof.B, proof.C) == (ref.A, ref.B, ref.C)
-    # x on the interpolation domain is refused (a Lagrange denominator would vanish)
+    mono = ps_api.Groth16Prove(tr.monomial_only(), q, dsol, r, s)  # the key as the reference makes it: coefficients
+    assert (mono.A, mono.B, mono.C) == (ref.A, ref.B, ref.C)
+    if n > 4:
+        bad = list(sol)
+        bad[4] = (bad[4] + 1) % pr.R
+        for key in (tr, tr.monomial_only()):
+            with pytest.raises(ps_api.Apocalypse):
+                ps_api.Groth16Prove(key, q, ps_api.Poly.upload(ctx, bad), r, s)
+    # x on the interpolation domain (or on the nodes n+1..2n-1 of the Lagrange form of XiT) is refused: a denominator would vanish
     with pytest.raises(ps_api.PlaysnarkError):
         ps_api.NewGroth16TrustedSetup(q, tox[0], tox[1], tox[2], 3, tox[4])
+    with pytest.raises(ps_api.PlaysnarkError):
+        ps_api.NewGroth16TrustedSetup(q, tox[0], tox[1], tox[2], n + 1, tox[4])
 
 
 @pytest.mark.parametrize("n", [4, 37, 200])
@@ -250,11 +268,15 @@ def test_phgr13_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     assert vk.vs.download() == G1.pack(want.VK.vs)
     assert vk.ws.download() == G2.pack(want.VK.ws)
     assert vk.ys.download() == G1.pack(want.VK.ys)
+    lam, _ = rs.lagrange_at(n - 1, (tox[0] - n) % pr.R)  # gsi in Lagrange form on the nodes n+1..2n-1
+    assert ek.lgsi.download() == b"".join(G1.to_b(G1.mul(v)) for v in lam)
     sol_dev = ps_api.Poly.upload(ctx, sol)
-    proof = ps_api.PHGR13Prove(ek, q, sol_dev)
+    proof = ps_api.PHGR13Prove(ek, q, sol_dev)  # h by its values over lgsi
     ref = rs.phgr13_prove(want.EK, c, sol, fast=n > 16)
+    mono = ps_api.PHGR13Prove(ek.monomial_only(), q, sol_dev)  # h by its coefficients over gsi, as the reference's key allows
     for f in ps_api.PHGR13Proof.FIELDS:
         assert getattr(proof, f) == getattr(ref, f), f
+        assert getattr(mono, f) == getattr(ref, f), f
     io = ps_api.Poly.upload(ctx, sol[:diff])
     args = (vk.vs.slice(0, diff), vk.ws.slice(0, diff), vk.ys.slice(0, diff))
     assert ps_api.PHGR13Verify(ctx, vk.fixed_points(), *args, proof, io)

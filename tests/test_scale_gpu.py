@@ -90,8 +90,17 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr, log2n):
     t0 = time.time()
     proof = ps_api.Groth16Prove(tr, q, dsol, r, s)
     t["groth16_prove_s"] = time.time() - t0
-    assert (proof.A, proof.B, proof.C) == (plain_proof.A, plain_proof.B, plain_proof.C)
     t["groth16_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
+    assert (proof.A, proof.B, proof.C) == (plain_proof.A, plain_proof.B, plain_proof.C)
+    # the key as the reference's setup makes it (monomial arrays only): coefficients, interpolations, the division
+    mono_key = tr.monomial_only()
+    ps_api.Groth16Prove(mono_key, q, dsol, r, s)
+    t0 = time.time()
+    mono = ps_api.Groth16Prove(mono_key, q, dsol, r, s)
+    t["groth16_prove_monomial_key_s"] = time.time() - t0
+    t["groth16_monomial_key_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
+    assert (mono.A, mono.B, mono.C) == (proof.A, proof.B, proof.C)
+    del mono_key
     progress("Groth16 proof")
 
     # ---- TestGroth16ProofGen at full size ----
@@ -142,8 +151,14 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr, log2n):
     t0 = time.time()
     pp = ps_api.PHGR13Prove(ek, q, dsol)
     t["phgr13_prove_s"] = time.time() - t0
+    mono_ek = ek.monomial_only()
+    ps_api.PHGR13Prove(mono_ek, q, dsol)
+    t0 = time.time()
+    mono_pp = ps_api.PHGR13Prove(mono_ek, q, dsol)
+    t["phgr13_prove_monomial_key_s"] = time.time() - t0
     for f in ps_api.PHGR13Proof.FIELDS:
         assert getattr(pp, f) == getattr(plain_pp, f), f
+        assert getattr(pp, f) == getattr(mono_pp, f), f
     t["phgr13_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
     progress("PHGR13 setup and proof")
     us, vs_, ws_, zs = rs.var_poly_evals(c, sp)
