@@ -714,22 +714,24 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     const dim3 dgrid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
     const int fold_neg = sc->neg_small ? 1 : 0, single = pl.sets == 1 ? 1 : 0;
     if (G <= SORT_MAX_BUCKETS) {  // two-level counting sort, no per-entry global atomics (msm.cuh 1'-3')
-        const u32 ncoarse = (u32)((G + SORT_FINE - 1) / SORT_FINE);
+        int fb = 5;  // fine bits: as few as keep the coarse bins within SORT_MAX_COARSE
+        while (((G + (1ull << fb) - 1) >> fb) > SORT_MAX_COARSE) fb++;
+        const u32 ncoarse = (u32)((G + (1ull << fb) - 1) >> fb);
         if ((rc = c->coarse.ensure(4 * (3 * (size_t)SORT_MAX_COARSE + 4)))) return rc;
         u32* coarse_cnt = (u32*)c->coarse.p;
         u32* coarse_off = coarse_cnt + SORT_MAX_COARSE + 1;
         u32* coarse_cur = coarse_off + SORT_MAX_COARSE + 1;
         HIP_TRY(hipMemsetAsync(coarse_cnt, 0, 4 * SORT_MAX_COARSE, st));
         hipLaunchKernelGGL(k_sort_count, dgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
-                           single, ncoarse, (u32*)c->ranks.p, coarse_cnt);
+                           single, ncoarse, fb, (u32*)c->ranks.p, coarse_cnt);
         PS_STAGE_MARK();  // 1: after digits + coarse histogram
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_MAX_COARSE), 0, st, (const u32*)coarse_cnt, ncoarse, coarse_off, coarse_cur,
                            (u32*)c->offs.p + G);
         hipLaunchKernelGGL(k_sort_partition, dgrid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, (const u32*)c->ranks.p,
-                           (u32)n, pl.NB, single, coarse_cur, (unsigned short*)c->keys.p, (u32*)c->vals.p);
+                           (u32)n, pl.NB, single, fb, coarse_cur, (unsigned short*)c->keys.p, (u32*)c->vals.p);
         PS_STAGE_MARK();  // 2: after scan + partition
         hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)c->vals.p,
-                           (const u32*)coarse_off, (u32)G, (u32*)c->offs.p, (u32*)c->sorted.p);
+                           (const u32*)coarse_off, (u32)G, fb, (u32*)c->offs.p, (u32*)c->sorted.p);
     } else {
         HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
         {

@@ -342,8 +342,10 @@ __global__ void __launch_bounds__(256) k_scatter(const u32* __restrict__ ent_key
 //   k_sort_scan       exclusive scan of the <= 1024 coarse bins
 //   k_sort_partition  entries grouped by coarse bin in LDS, one returning global add per (workgroup, bin)
 //                     reserves the run, coalesced writes of (fine key, value) into the bin's region
-//   k_sort_fine       one workgroup per coarse bin: LDS histogram of the 1024 fine keys, scan -> offs[],
+//   k_sort_fine       one workgroup per coarse bin: LDS histogram of its 2^fb fine keys, scan -> offs[],
 //                     second walk places the values: sorted[] and offs[] exactly as the old pipeline left them
+// fb (5..10 fine bits) is chosen so that there are several hundred coarse bins whatever the bucket count: a short-scalar
+// plan has 20 K buckets, and twenty workgroups walking 130 K entries each would leave the chip idle.
 // ---------------------------------------------------------------------------------------
 constexpr int SORT_FINE_BITS = 10;
 constexpr u32 SORT_FINE = 1u << SORT_FINE_BITS;
@@ -388,16 +390,20 @@ __device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, 
     return (mag - 1u) | ((d < 0 ? 0x80000000u : 0u) ^ flip);
 }
 
-// LDS counter updates with one shortcut: a wave whose active lanes all name the same counter (skewed scalars put
-// whole waves into one bucket) issues a single add instead of a 64-way conflict.  Must be called wave-uniformly.
+// LDS counter updates with one shortcut: the lanes that share the counter of the wave's first active lane are served by
+// ONE add when there are at least eight of them (a hot bucket -- the ones of a witness, a nearly empty top window -- puts
+// most of a wave onto one counter, and a 60-way same-address LDS atomic costs ~600 cycles); the rest go lane by lane.
+// Must be called wave-uniformly.
 __device__ inline void lds_count(u32* ctr, u32 bin, bool active) {
     const unsigned long long act = __ballot(active);
     if (!act) return;
     const int leader = __ffsll((long long)act) - 1;
     const u32 lb = __shfl(bin, leader, 64);
-    const unsigned long long same = __ballot(active && bin == lb);
-    if (same == act) {
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&ctr[lb], (u32)__popcll(act));
+    const bool mine = active && bin == lb;
+    const unsigned long long same = __ballot(mine);
+    if (__popcll(same) >= 8) {
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&ctr[lb], (u32)__popcll(same));
+        if (active && !mine) atomicAdd(&ctr[bin], 1u);
     } else if (active) {
         atomicAdd(&ctr[bin], 1u);
     }
@@ -408,13 +414,15 @@ __device__ inline u32 lds_rank(u32* ctr, u32 bin, bool active) {
     const int lane = (int)(threadIdx.x & 63);
     const int leader = __ffsll((long long)act) - 1;
     const u32 lb = __shfl(bin, leader, 64);
-    const unsigned long long same = __ballot(active && bin == lb);
+    const bool mine = active && bin == lb;
+    const unsigned long long same = __ballot(mine);
     u32 pos = 0;
-    if (same == act) {
+    if (__popcll(same) >= 8) {
         u32 b0 = 0;
-        if (lane == leader) b0 = atomicAdd(&ctr[lb], (u32)__popcll(act));
+        if (lane == leader) b0 = atomicAdd(&ctr[lb], (u32)__popcll(same));
         b0 = __shfl(b0, leader, 64);
-        pos = b0 + (u32)__popcll(act & ((1ull << lane) - 1ull));
+        if (mine) pos = b0 + (u32)__popcll(same & ((1ull << lane) - 1ull));
+        else if (active) pos = atomicAdd(&ctr[bin], 1u);
     } else if (active) {
         pos = atomicAdd(&ctr[bin], 1u);
     }
@@ -422,7 +430,7 @@ __device__ inline u32 lds_rank(u32* ctr, u32 bin, bool active) {
 }
 
 __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
-                                                               DigitConst cadd, int fold_neg, int single_set, u32 ncoarse,
+                                                               DigitConst cadd, int fold_neg, int single_set, u32 ncoarse, int fb,
                                                                u32* __restrict__ codes, u32* __restrict__ coarse_cnt) {
     __shared__ u32 hist[SORT_MAX_COARSE];
     const int w = blockIdx.y;
@@ -440,7 +448,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __rest
             codes[(size_t)w * n + i] = code;
         }
         const bool act = code != 0xffffffffu;
-        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> SORT_FINE_BITS, act);
+        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> fb, act);
     }
     __syncthreads();
     if (tid < ncoarse && hist[tid]) atomicAdd(&coarse_cnt[tid], hist[tid]);
@@ -457,7 +465,7 @@ __global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __rest
     if (tid == 0) { coarse_off[ncoarse] = total; *offs_total = total; }
 }
 
-__global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set,
+__global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set, int fb,
                                                                    u32* __restrict__ coarse_cur, unsigned short* __restrict__ part_key,
                                                                    u32* __restrict__ part_val) {
     __shared__ u32 hist[SORT_MAX_COARSE], binstart[SORT_MAX_COARSE], gbase[SORT_MAX_COARSE];
@@ -478,7 +486,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __
         const u32 i = chunk_base + j * DIGITS_THREADS + tid;
         const u32 code = i < n ? codes[(size_t)w * n + i] : 0xffffffffu;
         dig[j] = code;
-        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> SORT_FINE_BITS, code != 0xffffffffu);
+        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> fb, code != 0xffffffffu);
     }
     __syncthreads();
     // exclusive scan of the 1024 bins, one per thread; reserve each non-empty bin's run in its global region
@@ -503,7 +511,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __
         const u32 code = dig[j];
         const bool act = code != 0xffffffffu;
         const u32 key = key_base + (code & 0x7fffffffu);
-        const u32 pos = lds_rank(hist, key >> SORT_FINE_BITS, act);
+        const u32 pos = lds_rank(hist, key >> fb, act);
         if (act) {
             lkey[pos] = key;
             lval[pos] = (chunk_base + j * DIGITS_THREADS + tid) | (code & 0x80000000u) | wtag;
@@ -511,15 +519,15 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __
     }
     __syncthreads();
     for (u32 p = tid; p < total; p += DIGITS_THREADS) {
-        const u32 key = lkey[p], b = key >> SORT_FINE_BITS;
+        const u32 key = lkey[p], b = key >> fb;
         const u32 dst = gbase[b] + (p - binstart[b]);
-        part_key[dst] = (unsigned short)(key & (SORT_FINE - 1u));
+        part_key[dst] = (unsigned short)(key & ((1u << fb) - 1u));
         part_val[dst] = lval[p];
     }
 }
 
 __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* __restrict__ part_key, const u32* __restrict__ part_val,
-                                                         const u32* __restrict__ coarse_off, u32 G, u32* __restrict__ offs,
+                                                         const u32* __restrict__ coarse_off, u32 G, int fb, u32* __restrict__ offs,
                                                          u32* __restrict__ sorted) {
     __shared__ u32 hist[SORT_FINE];
     __shared__ u32 wtot[SORT_FINE / 64];
@@ -527,10 +535,21 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* _
     const u32 lo = coarse_off[p], hi = coarse_off[p + 1];
     hist[tid] = 0;
     __syncthreads();
-    for (u32 i0 = lo; i0 < hi; i0 += SORT_FINE) {
-        const u32 i = i0 + tid;
-        const bool act = i < hi;
-        lds_count(hist, act ? (u32)part_key[i] : 0u, act);
+    // Four strides per trip, loads first: a partition that holds a hot bucket is walked by ONE workgroup (10^5 entries of
+    // a witness's ones: 100 trips), and with one dependent global load per trip that walk was bound by memory latency
+    // (0.55 ms, as long as the accumulation of the whole sum).
+    constexpr u32 UNR = 4;
+    for (u32 i0 = lo; i0 < hi; i0 += UNR * SORT_FINE) {
+        u32 k[UNR];
+        bool act[UNR];
+#pragma unroll
+        for (u32 u = 0; u < UNR; u++) {
+            const u32 i = i0 + u * SORT_FINE + tid;
+            act[u] = i < hi;
+            k[u] = act[u] ? (u32)part_key[i] : 0u;
+        }
+#pragma unroll
+        for (u32 u = 0; u < UNR; u++) lds_count(hist, k[u], act[u]);
     }
     __syncthreads();
     const u32 cnt = hist[tid];
@@ -540,18 +559,26 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* _
     u32 before = 0;
     for (int q = 0; q < (int)(tid >> 6); q++) before += wtot[q];
     const u32 start = lo + before + inc - cnt;
-    const u32 g = p * SORT_FINE + tid;
-    if (g < G) offs[g] = start;
+    const u32 g = (p << fb) + tid;  // threads beyond the partition's 2^fb buckets own no bin (their count is 0)
+    if (tid < (1u << fb) && g < G) offs[g] = start;
     __syncthreads();
     hist[tid] = start;  // cursor
     __syncthreads();
-    for (u32 i0 = lo; i0 < hi; i0 += SORT_FINE) {
-        const u32 i = i0 + tid;
-        const bool act = i < hi;
-        const u32 k = act ? (u32)part_key[i] : 0u;
-        const u32 v = act ? part_val[i] : 0u;
-        const u32 pos = lds_rank(hist, k, act);
-        if (act) sorted[pos] = v;
+    for (u32 i0 = lo; i0 < hi; i0 += UNR * SORT_FINE) {
+        u32 k[UNR], v[UNR];
+        bool act[UNR];
+#pragma unroll
+        for (u32 u = 0; u < UNR; u++) {
+            const u32 i = i0 + u * SORT_FINE + tid;
+            act[u] = i < hi;
+            k[u] = act[u] ? (u32)part_key[i] : 0u;
+            v[u] = act[u] ? part_val[i] : 0u;
+        }
+#pragma unroll
+        for (u32 u = 0; u < UNR; u++) {
+            const u32 pos = lds_rank(hist, k[u], act[u]);
+            if (act[u]) sorted[pos] = v[u];
+        }
     }
 }
 
