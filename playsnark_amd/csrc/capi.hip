@@ -717,21 +717,32 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         int fb = 5;  // fine bits: as few as keep the coarse bins within SORT_MAX_COARSE
         while (((G + (1ull << fb) - 1) >> fb) > SORT_MAX_COARSE) fb++;
         const u32 ncoarse = (u32)((G + (1ull << fb) - 1) >> fb);
-        if ((rc = c->coarse.ensure(4 * (3 * (size_t)SORT_MAX_COARSE + 4)))) return rc;
+        if ((rc = c->coarse.ensure(4 * (4 * (size_t)SORT_MAX_COARSE + 8)))) return rc;
         u32* coarse_cnt = (u32*)c->coarse.p;
         u32* coarse_off = coarse_cnt + SORT_MAX_COARSE + 1;
         u32* coarse_cur = coarse_off + SORT_MAX_COARSE + 1;
+        u32* tile_base = coarse_cur + SORT_MAX_COARSE + 1;
         HIP_TRY(hipMemsetAsync(coarse_cnt, 0, 4 * SORT_MAX_COARSE, st));
+        HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));  // per-bucket counters of the big bins (k_sort_big_*)
         hipLaunchKernelGGL(k_sort_count, dgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
                            single, ncoarse, fb, (u32*)c->ranks.p, coarse_cnt);
         PS_STAGE_MARK();  // 1: after digits + coarse histogram
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_MAX_COARSE), 0, st, (const u32*)coarse_cnt, ncoarse, coarse_off, coarse_cur,
-                           (u32*)c->offs.p + G);
+                           (u32*)c->offs.p + G, tile_base);
         hipLaunchKernelGGL(k_sort_partition, dgrid, dim3(DIGITS_THREADS), 2 * DIGITS_CHUNK * sizeof(u32), st, (const u32*)c->ranks.p,
                            (u32)n, pl.NB, single, fb, coarse_cur, (unsigned short*)c->keys.p, (u32*)c->vals.p);
         PS_STAGE_MARK();  // 2: after scan + partition
         hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)c->vals.p,
                            (const u32*)coarse_off, (u32)G, fb, (u32*)c->offs.p, (u32*)c->sorted.p);
+        // bins with more than SORT_BIG entries, tile by tile (no tiles: the three kernels return at once)
+        const unsigned big_grid = (unsigned)std::min<u64>(2048, total / SORT_TILE + 1);
+        hipLaunchKernelGGL(k_sort_big_count, dim3(big_grid), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)coarse_off,
+                           (const u32*)tile_base, ncoarse, fb, (u32*)c->counts.p);
+        hipLaunchKernelGGL(k_sort_big_scan, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const u32*)coarse_off, (u32)G, fb, (u32*)c->counts.p,
+                           (u32*)c->offs.p);
+        hipLaunchKernelGGL(k_sort_big_scatter, dim3(big_grid), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p,
+                           (const u32*)c->vals.p, (const u32*)coarse_off, (const u32*)tile_base, ncoarse, fb, (u32*)c->counts.p,
+                           (u32*)c->sorted.p);
     } else {
         HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
         {

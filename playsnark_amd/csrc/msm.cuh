@@ -454,15 +454,31 @@ __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __rest
     if (tid < ncoarse && hist[tid]) atomicAdd(&coarse_cnt[tid], hist[tid]);
 }
 
+// A coarse bin that holds more than SORT_BIG entries (hot buckets: all-equal scalars, the wire values of a boolean
+// circuit, a carry-only window) is not walked by its one workgroup -- 2^19 entries took it 1.5 ms -- but cut into tiles of
+// SORT_TILE entries that any workgroup takes: k_sort_big_count (LDS histogram per tile, one global add per (tile, bucket)),
+// k_sort_big_scan (per big bin: scan of its 2^fb counters), k_sort_big_scatter (per tile: one returning add per (tile,
+// bucket) reserves the run, LDS ranks inside it).
+constexpr u32 SORT_BIG = 1u << 16;
+constexpr u32 SORT_TILE = 1u << 14;
+
 // one workgroup: coarse_off = exclusive scan of coarse_cnt, coarse_cur = a copy (the partition kernel's cursors),
-// grand total -> coarse_off[ncoarse] and offs[G]
+// grand total -> coarse_off[ncoarse] and offs[G]; tile_base = exclusive scan of the big bins' tile counts
 __global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __restrict__ coarse_cnt, u32 ncoarse, u32* __restrict__ coarse_off,
-                                                               u32* __restrict__ coarse_cur, u32* __restrict__ offs_total) {
+                                                               u32* __restrict__ coarse_cur, u32* __restrict__ offs_total,
+                                                               u32* __restrict__ tile_base) {
     const u32 tid = threadIdx.x;
+    const u32 cnt = tid < ncoarse ? coarse_cnt[tid] : 0u;
     u32 total;
-    const u32 ex = block_excl_scan(tid < ncoarse ? coarse_cnt[tid] : 0u, &total);
+    const u32 ex = block_excl_scan(cnt, &total);
     if (tid < ncoarse) { coarse_off[tid] = ex; coarse_cur[tid] = ex; }
     if (tid == 0) { coarse_off[ncoarse] = total; *offs_total = total; }
+    __syncthreads();
+    const u32 tiles = cnt > SORT_BIG ? (cnt + SORT_TILE - 1) / SORT_TILE : 0u;
+    u32 ttotal;
+    const u32 tex = block_excl_scan(tiles, &ttotal);
+    if (tid < ncoarse) tile_base[tid] = tex;
+    if (tid == 0) tile_base[ncoarse] = ttotal;
 }
 
 __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set, int fb,
@@ -533,6 +549,7 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* _
     __shared__ u32 wtot[SORT_FINE / 64];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     const u32 lo = coarse_off[p], hi = coarse_off[p + 1];
+    if (hi - lo > SORT_BIG) return;  // a big bin: the tile kernels below
     hist[tid] = 0;
     __syncthreads();
     // Four strides per trip, loads first: a partition that holds a hot bucket is walked by ONE workgroup (10^5 entries of
@@ -579,6 +596,98 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* _
             const u32 pos = lds_rank(hist, k[u], act[u]);
             if (act[u]) sorted[pos] = v[u];
         }
+    }
+}
+
+// tile t of the big bins: its bin p (tile_base[p] <= t < tile_base[p+1]) and its entry range
+__device__ inline bool sort_big_tile(u32 t, const u32* __restrict__ tile_base, const u32* __restrict__ coarse_off, u32 ncoarse,
+                                     u32* p_out, u32* lo_out, u32* hi_out) {
+    if (t >= tile_base[ncoarse]) return false;
+    u32 lo = 0, hi = ncoarse;  // tile_base[lo] <= t < tile_base[hi]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (tile_base[mid] <= t) lo = mid; else hi = mid;
+    }
+    // bins without tiles repeat their successor's base: step to the bin that owns tile t
+    while (tile_base[lo + 1] <= t) lo++;
+    const u32 first = coarse_off[lo] + (t - tile_base[lo]) * SORT_TILE, end = coarse_off[lo + 1];
+    *p_out = lo;
+    *lo_out = first;
+    *hi_out = end - first > SORT_TILE ? first + SORT_TILE : end;
+    return true;
+}
+constexpr u32 SORT_TILE_PER_THREAD = SORT_TILE / SORT_FINE;  // 16
+
+__global__ void __launch_bounds__(SORT_FINE) k_sort_big_count(const unsigned short* __restrict__ part_key, const u32* __restrict__ coarse_off,
+                                                              const u32* __restrict__ tile_base, u32 ncoarse, int fb,
+                                                              u32* __restrict__ gcnt) {
+    __shared__ u32 hist[SORT_FINE];
+    const u32 tid = threadIdx.x;
+    for (u32 t = blockIdx.x;; t += gridDim.x) {
+        u32 p, lo, hi;
+        if (!sort_big_tile(t, tile_base, coarse_off, ncoarse, &p, &lo, &hi)) return;
+        hist[tid] = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (u32 j = 0; j < SORT_TILE_PER_THREAD; j++) {
+            const u32 i = lo + j * SORT_FINE + tid;
+            const bool act = i < hi;
+            lds_count(hist, act ? (u32)part_key[i] : 0u, act);
+        }
+        __syncthreads();
+        if (tid < (1u << fb) && hist[tid]) atomicAdd(&gcnt[((size_t)p << fb) + tid], hist[tid]);
+        __syncthreads();
+    }
+}
+// per big bin: offs[] of its buckets, and the same values left in gcnt[] as the scatter's cursors
+__global__ void __launch_bounds__(SORT_FINE) k_sort_big_scan(const u32* __restrict__ coarse_off, u32 G, int fb, u32* __restrict__ gcnt,
+                                                             u32* __restrict__ offs) {
+    __shared__ u32 wtot[SORT_FINE / 64];
+    const u32 p = blockIdx.x, tid = threadIdx.x;
+    const u32 lo = coarse_off[p], hi = coarse_off[p + 1];
+    if (hi - lo <= SORT_BIG) return;
+    const u32 g = (p << fb) + tid;
+    const bool own = tid < (1u << fb) && g < G;
+    const u32 cnt = own ? gcnt[g] : 0u;
+    const u32 inc = wave_incl_scan(cnt);
+    if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+    __syncthreads();
+    u32 before = 0;
+    for (int q = 0; q < (int)(tid >> 6); q++) before += wtot[q];
+    const u32 start = lo + before + inc - cnt;
+    if (own) { offs[g] = start; gcnt[g] = start; }
+}
+__global__ void __launch_bounds__(SORT_FINE) k_sort_big_scatter(const unsigned short* __restrict__ part_key, const u32* __restrict__ part_val,
+                                                                const u32* __restrict__ coarse_off, const u32* __restrict__ tile_base,
+                                                                u32 ncoarse, int fb, u32* __restrict__ gcur, u32* __restrict__ sorted) {
+    __shared__ u32 hist[SORT_FINE];
+    const u32 tid = threadIdx.x;
+    for (u32 t = blockIdx.x;; t += gridDim.x) {
+        u32 p, lo, hi;
+        if (!sort_big_tile(t, tile_base, coarse_off, ncoarse, &p, &lo, &hi)) return;
+        hist[tid] = 0;
+        __syncthreads();
+        u32 k[SORT_TILE_PER_THREAD];
+#pragma unroll
+        for (u32 j = 0; j < SORT_TILE_PER_THREAD; j++) {
+            const u32 i = lo + j * SORT_FINE + tid;
+            const bool act = i < hi;
+            k[j] = act ? (u32)part_key[i] : 0xffffffffu;
+            lds_count(hist, act ? k[j] : 0u, act);
+        }
+        __syncthreads();
+        // this tile's run inside every bucket it touches: one returning global add per (tile, bucket)
+        const u32 cnt = hist[tid];
+        __syncthreads();
+        hist[tid] = (tid < (1u << fb) && cnt) ? atomicAdd(&gcur[((size_t)p << fb) + tid], cnt) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < SORT_TILE_PER_THREAD; j++) {
+            const bool act = k[j] != 0xffffffffu;
+            const u32 pos = lds_rank(hist, act ? k[j] : 0u, act);
+            if (act) sorted[pos] = part_val[lo + j * SORT_FINE + tid];
+        }
+        __syncthreads();
     }
 }
 
@@ -667,6 +776,22 @@ __device__ inline Affine<KF> ld_entry_point(const char* __restrict__ points, u32
     return ld_affine<KF>(reinterpret_cast<const Affine<typename FieldTraits<KF>::Store>*>(points + row * pstride));
 }
 
+// Bucket that holds sorted position p (> the current bucket's end): usually the next one; behind a run of EMPTY buckets --
+// skewed scalars leave most of 2^19 buckets empty, and walking them one dependent load at a time cost 40 ms on the wire
+// values of a boolean circuit -- a binary search over offs[].
+__device__ inline void next_bucket(const u32* __restrict__ offs, u32 G, u32 p, u32& g, u32& bend) {
+    g++;
+    bend = offs[g + 1];
+    if (bend > p) return;
+    u32 lo = g + 1, hi = G;  // offs[lo] <= p < offs[hi]
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (offs[mid] <= p) lo = mid; else hi = mid;
+    }
+    g = lo;
+    bend = offs[g + 1];
+}
+
 // PREFETCH: the next entry's point is requested before the current addition starts (28 more VGPRs), so that
 // the ~2 us of an HBM gather hide under the ~7 us of the addition even when both waves of a SIMD miss together.
 template <class KF, bool PREFETCH>
@@ -704,7 +829,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const char* __restrict__ 
                 flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
                 acc = xyzz_identity<KF>();
                 run_start = p;
-                do { g++; bend = offs[g + 1]; } while (bend <= p);
+                next_bucket(offs, G, p, g, bend);
             }
             if (!affine_is_identity<KF>(pt)) {
                 if (e >> 31) pt.y = f_neg(pt.y);
@@ -718,7 +843,7 @@ __global__ void __launch_bounds__(256, 2) k_accumulate(const char* __restrict__ 
                 flush_run<KF>(acc, g, run_start, p, start, t, offs, buckets, parts);
                 acc = xyzz_identity<KF>();
                 run_start = p;
-                do { g++; bend = offs[g + 1]; } while (bend <= p);
+                next_bucket(offs, G, p, g, bend);
             }
             const u32 e = sorted[p];
             Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);

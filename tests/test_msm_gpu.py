@@ -647,3 +647,30 @@ def test_window_table_full_size_bit_exact_vs_oracle(ps_api, ctx, co, pr):
     m = 1 << 16
     small = ps_api.Points.upload(ctx, ps_api.G1, raw[: 96 * m]).precompute(18)
     assert ps_api.Poly.upload(ctx, sc[: 32 * m]).BlindEval(small) == co.G1.to_b(co.G1.msm_pippenger(sc[: 32 * m], raw[: 96 * m], m, threads))
+
+
+def test_wire_values_of_a_boolean_circuit_over_a_window_table(ps_api, ctx, co, pr):
+    """Scalars that are all 0 or 1 (the values L.s of booleanity gates, which a Lagrange-form key makes the scalars of the
+    sums) put 2^19 entries into ONE of 2^19 buckets: correct bytes, and no walk over the empty buckets (that walk, one
+    dependent load per bucket, once cost 40 ms per sum; the bound below is ten times what the sum takes)."""
+    import time
+
+    import numpy as np
+
+    n = 1 << 20
+    raw_seeds = _uniform_be32(n, 1212).tobytes()
+    pts = ps_api.Points.from_scalars(ctx, ps_api.G1, ps_api.Poly.upload(ctx, raw_seeds)).precompute()
+    bits = np.random.RandomState(5).randint(0, 2, size=n).astype(np.uint8)
+    rows = np.zeros((n, 32), dtype=np.uint8)
+    rows[:, 31] = bits
+    sc = ps_api.Poly.upload(ctx, rows.tobytes())
+    sc.BlindEval(pts)  # warm-up
+    ctx.sync()
+    t0 = time.perf_counter()
+    got = sc.BlindEval(pts)
+    ms = (time.perf_counter() - t0) * 1e3
+    # sum of the selected points = (sum of their discrete logs) G
+    seeds = np.frombuffer(raw_seeds, dtype=np.uint8).reshape(n, 32)
+    total = sum(int.from_bytes(seeds[i].tobytes(), "big") for i in np.nonzero(bits)[0]) % pr.R
+    assert got == co.G1.to_b(co.G1.mul(total))
+    assert ms < 25, f"{ms:.1f} ms for a 2^20-point sum of 0/1 scalars"

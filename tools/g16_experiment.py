@@ -6,12 +6,20 @@ from playsnark_amd import api
 ctx = api.Context(0)
 if os.environ.get("NOTAB"): ctx.set_tables(False)
 n = 1 << 20
-nvars, L, Rm, O, sol = bench.synthetic_r1cs(n)
-q = api.QAP.from_csr(ctx, nvars, nvars - 3, L, Rm, O)
+if os.environ.get("CIRCUIT") == "bits":  # n booleanity gates b*b = b over [const, b_1..b_n], a witness of random bits
+    import numpy as np
+    ptr = np.arange(n + 1, dtype=np.uint32); col = np.arange(1, n + 1, dtype=np.uint32); val = np.ones(n, dtype=np.int64)
+    nvars, L, Rm, O = n + 1, (ptr, col, val), (ptr, col, val), (ptr, col, val)
+    sol = [1] + np.random.RandomState(7).randint(0, 2, size=n).tolist()
+    q = api.QAP.from_csr(ctx, nvars, n, L, Rm, O)
+else:
+    nvars, L, Rm, O, sol = bench.synthetic_r1cs(n)
+    q = api.QAP.from_csr(ctx, nvars, nvars - 3, L, Rm, O)
 rnd = random.Random(1)
 fr = lambda: rnd.randrange(1 << 20, bench.R_MOD)
 dsol = api.Poly.upload(ctx, sol)
 tr, vk = api.NewGroth16TrustedSetup(q, fr(), fr(), fr(), fr(), fr())
+if os.environ.get("MONOMIAL"): tr = tr.monomial_only()
 r, s = fr(), fr()
 api.Groth16Prove(tr, q, dsol, r, s)
 api.Groth16Prove(tr, q, dsol, r, s)
