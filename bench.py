@@ -525,7 +525,40 @@ def extras(api, ctx, args):
     ok = api.PHGR13Verify(ctx, pvk.fixed_points(), *io_arrays, pp, io)
     out["phgr13_prove_2p20"] = {"ms": ph_ms, "phase_ms": ctx.last_prove_phase_ms(), "verified_by_pairing": bool(ok),
                                 "key": "gsi also in Lagrange form (ps_phgr13_ek.lgsi)", "monomial_key": {"ms": ph_mono_ms}}
+    del ek, pvk, pp, q, dsol
+
+    # ---- the regime the reference itself lives in (Vector = []int, algebra.go:13): 2^20 booleanity gates b*b = b, a witness
+    # of random bits uploaded as int64 -- short scalars, and wire values that are all 0 or 1 ----
+    import numpy as np
+
+    ptr = np.arange(n + 1, dtype=np.uint32)
+    col = np.arange(1, n + 1, dtype=np.uint32)
+    val = np.ones(n, dtype=np.int64)
+    q = api.QAP.from_csr(ctx, n + 1, n, (ptr, col, val), (ptr, col, val), (ptr, col, val))
+    bits = [1] + np.random.RandomState(7).randint(0, 2, size=n).tolist()
+    dsol = api.Poly.from_values(ctx, bits)
+    tr, vk = api.NewGroth16TrustedSetup(q, fr(), fr(), fr(), fr(), fr())
+    g_ms, _, proof = timed_g16_on(api, ctx, tr, q, dsol, r, s)
+    ok = api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, vk["Gamma"], tr.Delta2, vk["IoLP"], proof, api.Poly.from_values(ctx, bits[:1]))
+    del tr, vk
+    ek, pvk = api.NewPHGR13TrustedSetup(q, *[fr() for _ in range(8)])
+    api.PHGR13Prove(ek, q, dsol)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        api.PHGR13Prove(ek, q, dsol)
+    p_ms = (time.perf_counter() - t0) / 3 * 1e3
+    out["boolean_circuit_2p20_int64_witness"] = {"groth16_ms": g_ms, "phgr13_ms": p_ms, "groth16_verified_by_pairing": bool(ok)}
     return out
+
+
+def timed_g16_on(api, ctx, key, q, dsol, r, s):
+    api.Groth16Prove(key, q, dsol, r, s)
+    ph = []
+    t0 = time.perf_counter()
+    for _ in range(3):
+        pf = api.Groth16Prove(key, q, dsol, r, s)
+        ph.append(ctx.last_prove_phase_ms())
+    return (time.perf_counter() - t0) / 3 * 1e3, ph, pf
 
 
 if __name__ == "__main__":
