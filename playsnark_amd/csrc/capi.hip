@@ -64,7 +64,7 @@ struct DevBuf {
     }
 };
 
-constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>);  // window sums of one MSM (W <= 64)
+constexpr size_t PS_PINNED_SLOT = 256 * sizeof(Xyzz<Fp2>);  // partial results of one MSM's reduction (sets * jobs <= 256)
 
 struct ps_ctx {
     int device = 0;
@@ -781,12 +781,9 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const u64 total = (u64)pl.W * n;
     const u64 G = pl.G;
     const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
-    const u32 segs_per_win = pl.NB >> RED_SEG_LOG;
-    const u32 nseg_total = segs_per_win * (u32)pl.sets;
-    const int red_bits = pl.c - 1 - RED_SEG_LOG;  // log2(segs_per_win)
-    const u32 l2_jobs = (u32)pl.sets * (u32)(red_bits + 1);
-    // a reduction job sums segs_per_win (or half as many) points: more than 4096 are cut into pieces (k_reduce_l2b)
-    const u32 l2_split = segs_per_win > 8192 ? std::min<u32>(64u, segs_per_win / 4096u) : 1u;
+    const ReducePlan rp = reduce_plan(pl.NB);
+    const u32 nseg_total = rp.segs * (u32)pl.sets;
+    const u32 per_role = rp.m * (u32)pl.sets, nres = rp.njobs * (u32)pl.sets;
     const bool tab = pl.sets == 1;
     const u32 pstride = tab ? (u32)table_row_bytes(pts->group) : (u32)sizeof(Affine<F>);
     const char* src = tab ? (const char*)pts->st->table + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
@@ -795,14 +792,14 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     int rc;
     if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
-    if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + (size_t)l2_jobs * (l2_split + 1))))) return rc;
-    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)pl.sets))) return rc;
+    if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + 5 * (size_t)per_role + (size_t)nres * rp.nblk)))) return rc;
+    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)nres))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
     const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
-    if (sizeof(Xyzz<F>) * (size_t)pl.sets > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
+    if (sizeof(Xyzz<F>) * (size_t)nres > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
@@ -836,21 +833,21 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     {
         Xyzz<F>* accs = (Xyzz<F>*)wc->segs.p;
         Xyzz<F>* runs = accs + nseg_total;
-        Xyzz<F>* l2 = runs + nseg_total;
+        Xyzz<F>* lvl = runs + nseg_total;
+        Xyzz<F>* pieces = lvl + 5 * (size_t)per_role;
         hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
                            nseg_total, accs, runs);
-        Xyzz<F>* pieces = l2 + l2_jobs;
-        hipLaunchKernelGGL(k_reduce_l2<KF>, dim3(l2_jobs * l2_split), dim3(512), (512 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)accs,
-                           (const Xyzz<F>*)runs, segs_per_win, red_bits, l2_split, l2_split > 1 ? pieces : l2);
-        if (l2_split > 1)
-            hipLaunchKernelGGL(k_reduce_l2b<KF>, dim3(l2_jobs), dim3(64 * LN), 64 * sizeof(Xyzz<F>), st, (const Xyzz<F>*)pieces, red_bits,
-                               l2_split, l2);
-        hipLaunchKernelGGL(k_reduce_l3<KF>, dim3((unsigned)pl.sets), dim3(RED_L3_THREADS * LN), RED_L3_THREADS * sizeof(Xyzz<F>), st,
-                           (const Xyzz<F>*)l2, red_bits, (Xyzz<F>*)wc->wins.p);
+        hipLaunchKernelGGL(k_reduce_pyr<KF>, dim3(nblocks(5 * (size_t)per_role * LN)), dim3(256), 0, st, (const Xyzz<F>*)accs,
+                           (const Xyzz<F>*)runs, rp.segs, rp.m, (u32)pl.sets, lvl);
+        hipLaunchKernelGGL(k_reduce_sum<KF>, dim3(nres * rp.nblk), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                           (const Xyzz<F>*)lvl, rp.m, (u32)pl.sets, rp.njobs, rp.nblk, rp.nblk > 1 ? pieces : (Xyzz<F>*)wc->wins.p);
+        if (rp.nblk > 1)
+            hipLaunchKernelGGL(k_reduce_fin<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                               (const Xyzz<F>*)pieces, rp.nblk, (Xyzz<F>*)wc->wins.p);
     }
     PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * pl.sets,
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * nres,
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(wc->ev_tail_done, st));
     wc->tail_used = true;
@@ -891,11 +888,22 @@ static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc
 
 template <class F>
 static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) {
-    const Xyzz<F>* wins = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
+    // per bucket set the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6):
+    //   set sum = A + 8 * (Q0 + 2 Q1 + 4 Q2 + 8 * sum_k 2^k T_k)
+    const Xyzz<F>* res = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
+    const ReducePlan rp = reduce_plan(pl.NB);
     Xyzz<F> acc = xyzz_identity<F>();
     for (int w = pl.sets - 1; w >= 0; w--) {  // one set (window table): the sum itself
+        const Xyzz<F>* r = res + (size_t)w * rp.njobs;
+        Xyzz<F> s = xyzz_identity<F>();
+        for (int j = (int)rp.njobs - 1; j >= 1; j--) {
+            s = xyzz_dbl<F>(s);
+            xyzz_add<F>(s, r[j]);
+        }
+        for (int i = 0; i < RED_SEG_LOG; i++) s = xyzz_dbl<F>(s);
+        xyzz_add<F>(s, r[0]);
         for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, wins[w]);
+        xyzz_add<F>(acc, s);
     }
     write_affine(out, acc);
 }

@@ -14,9 +14,10 @@
 //                   flushing whenever the bucket id changes.  Buckets that lie inside one slice
 //                   are final; runs cut by a slice boundary go to a head/tail partial slot.
 //   5 k_fixup       per bucket: add up the partial slots of the slices it spans
-//   6 k_reduce_l1/l2/l3  per window  sum_b (b+1)*B[b]: 8-bucket running sums, then parallel tree sums
-//                   per weight bit, then a short Horner (dependency depth ~16 + ~16 + ~2c instead of 100+)
-//   host            Horner over the W window sums (c doublings each) and affine normalisation
+//   6 k_reduce_l1/pyr/sum/fin  per bucket set  sum_b (b+1)*B[b]: 8-bucket running sums, then sums by the bits of the
+//     segment index; their weights 2^k are applied on the host
+//   host            the weights of the reduction's partial results, Horner over the W window sums (c doublings each)
+//                   and affine normalisation
 //
 // Data layout in HBM: points AoS affine Montgomery, 14 x 28-bit limbs per coordinate (112 B G1 /
 // 224 B G2, 16-B aligned, read with dwordx4 loads); scalars 8 x u32 little-endian plain; keys/ranks/sorted as [W][n] u32 so the
@@ -984,17 +985,46 @@ __global__ void __launch_bounds__(256) k_fixup_heavy(const Xyzz<typename FieldTr
 // ---------------------------------------------------------------------------------------
 // 6. bucket reduction: window sum = sum_{b=0}^{NB-1} (b+1) * B[b]
 // ---------------------------------------------------------------------------------------
-// A point addition is ~14 dependent multiplications (tens of microseconds per lane), so this phase
-// is bound by the length of its dependency chains, not by work.  Three short levels:
-//   L1  one thread per segment of 8 buckets: running sums  acc_s = sum (b-8s+1) B[b],
-//       run_s = sum B[b]                                   (depth 16, W*NB/8 threads)
-//   L2  window sum = sum_s acc_s + 8 * sum_s s*run_s, and s*run_s is split by the bits of s:
-//       T_k = sum over {s : bit k of s} run_s.  One block per (window, job): job 0 sums the
-//       acc_s, job k+1 sums T_k -- plain tree sums (depth ~ 8 + log2 256) -- and then doubles its
-//       result k + 3 times (all jobs in parallel: depth <= c - 2 doublings)
-//   L3  one block per window: tree sum of the c - 3 weighted job results (depth 5)
+// A point addition is ~14 multiplications (about 16 us for a wave, alone on its SIMD or not), and a sum that is
+// pipelined behind others pays for every wave-step of this phase: the levels are chosen for little work first, short
+// dependency chains second.  With segs = NB / 8 segments per bucket set and m = max(1, segs / 8):
+//   L1   one thread per segment of 8 buckets: running sums  acc_s = sum (b-8s+1) B[b], run_s = sum B[b]
+//        (14 additions deep, NB/8 threads; window sum = sum_s acc_s + 8 * sum_s s * run_s)
+//   PYR  the weight s = 8 j + i of run_s is split into its low three bits and j: five sums over each group of 8
+//        segments, one thread each -- A1_j = sum_i acc, Q0_j / Q1_j / Q2_j = sum of the run_s whose i has bit 0 / 1 / 2,
+//        R1_j = sum_i run (3 or 7 additions deep, 5 m threads)
+//   SUM  per bucket set 4 + log2(m) jobs: the plain sums of A1, Q0, Q1, Q2 over j and, for every bit k of j, T_k = the
+//        sum of the R1_j whose j has bit k.  512 terms per workgroup of 64 (8 in a row, then an LDS tree), the pieces of
+//        a job summed by FIN.  (Round 1 summed all 2^(c-4) run_s once per bit of s: 8.5 additions per segment where
+//        this takes 23/8 + 7.5/8.)
+//   host the weights: sum = A + sum_q 2^(q+3) Q_q + sum_k 2^(k+6) T_k, a Horner chain of c-1 doublings per bucket set
+//        that takes the CPU a few tens of microseconds (msm_fold_host) and was 19 dependent doublings, 0.3 ms, on a GPU
+//        lane.
 constexpr int RED_SEG_LOG = 3;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
+constexpr int RED_DIRECT_JOBS = 4;   // A, Q0, Q1, Q2
+constexpr u32 RED_SUM_LANES = 64;    // logical threads of a SUM / FIN workgroup
+constexpr u32 RED_SUM_TERMS = 512;   // terms of a direct job per SUM workgroup
+
+struct ReducePlan {
+    u32 segs;   // segments (of RED_SEG buckets) per bucket set
+    u32 m;      // groups of 8 segments per bucket set
+    int kb;     // log2(m): bit jobs
+    u32 njobs;  // RED_DIRECT_JOBS + kb results per bucket set, in the order A, Q0, Q1, Q2, T_0 .. T_{kb-1}
+    u32 nblk;   // SUM workgroups per job
+};
+static inline ReducePlan reduce_plan(u32 NB) {
+    ReducePlan r;
+    r.segs = NB >> RED_SEG_LOG;
+    r.m = r.segs >= 8 ? r.segs / 8 : 1;
+    r.kb = 0;
+    while ((1u << r.kb) < r.m) r.kb++;
+    r.njobs = RED_DIRECT_JOBS + (u32)r.kb;
+    r.nblk = r.m / RED_SUM_TERMS;
+    if (r.nblk < 1) r.nblk = 1;
+    if (r.nblk > RED_SUM_LANES) r.nblk = RED_SUM_LANES;
+    return r;
+}
 
 template <class KF>
 __global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
@@ -1021,76 +1051,69 @@ __global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldT
     st_xyzz<KF>(&runs[idx], x);
 }
 
+// lvl: five arrays of sets * m points (A1, Q0, Q1, Q2, R1).  Logical thread = (role, set, j); the roles are laid out
+// one after the other so that a wave runs one role.
 template <class KF>
-__global__ void __launch_bounds__(512) k_reduce_l2(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
-                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
-                                                   u32 segs_per_win, int nbits, u32 nsplit,
-                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
-    // grid = windows * (nbits + 1) jobs * nsplit: a job of a long window (one bucket set of 2^19 buckets has 65536
-    // segments) is cut into nsplit blocks so that no thread adds more than a few terms in a row; the pieces are
-    // summed, and the job's weight applied, by k_reduce_l2b.  nsplit == 1: the weight is applied here.
+__global__ void __launch_bounds__(256, 1) k_reduce_pyr(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
+                                                       const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
+                                                       u32 segs, u32 m, u32 sets,
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ lvl) {
+    const u32 per_role = sets * m;
+    const u32 L = logical_tid<KF>();
+    if (L >= 5u * per_role) return;
+    const u32 role = L / per_role, id = L % per_role;
+    const u32 set = id / m, j = id % m;
+    const u32 mask = role == 1 ? 0xAAu : role == 2 ? 0xCCu : role == 3 ? 0xF0u : 0xFFu;
+    const Xyzz<typename FieldTraits<KF>::Store>* src = (role == 0 ? accs : runs) + (size_t)set * segs + (size_t)j * 8;
+    const u32 valid = segs < 8 ? segs : 8;
+    Xyzz<KF> acc = xyzz_identity<KF>();
+    for (u32 i = 0; i < valid; i++) {
+        if (!((mask >> i) & 1u)) continue;
+        Xyzz<KF> v = ld_xyzz<KF>(&src[i]);
+        xyzz_add_inl<KF>(acc, v);
+    }
+    st_xyzz<KF>(&lvl[(size_t)role * per_role + id], acc);
+}
+
+// grid = sets * njobs * nblk workgroups of RED_SUM_LANES logical threads; out[(set * njobs + job) * nblk + blk]
+template <class KF>
+__global__ void __launch_bounds__(128) k_reduce_sum(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ lvl, u32 m, u32 sets,
+                                                    u32 njobs, u32 nblk, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 split = blockIdx.x % nsplit, wj = blockIdx.x / nsplit;
-    const u32 w = wj / (u32)(nbits + 1), job = wj % (u32)(nbits + 1);
-    const u32 lt = logical_local<KF>(), lb = logical_block<KF>();
+    const u32 blk = blockIdx.x % nblk, job = (blockIdx.x / nblk) % njobs, set = blockIdx.x / (nblk * njobs);
+    const u32 lt = logical_local<KF>();
+    const bool direct = job < (u32)RED_DIRECT_JOBS;
+    const u32 arr = direct ? job : (u32)RED_DIRECT_JOBS;  // bit jobs read R1
+    const Xyzz<S>* src = lvl + (size_t)arr * sets * m + (size_t)set * m;
+    const u32 cnt = direct ? m : m >> 1;
+    const u32 chunk = (cnt + nblk - 1) / nblk;
+    const u32 k = direct ? 0u : job - (u32)RED_DIRECT_JOBS;
+    const u32 low = (1u << k) - 1u;
+    u32 t_end = (blk + 1) * chunk;
+    if (t_end > cnt) t_end = cnt;
     Xyzz<KF> acc = xyzz_identity<KF>();
-    if (job == 0) {
-        const u32 chunk = segs_per_win / nsplit;
-        for (u32 s = split * chunk + lt; s < (split + 1) * chunk; s += lb) {
-            Xyzz<KF> v = ld_xyzz<KF>(&accs[(size_t)w * segs_per_win + s]);
-            xyzz_add_inl<KF>(acc, v);
-        }
-    } else {
-        const int k = (int)job - 1;  // enumerate the s with bit k set: insert a 1 at position k of t
-        const u32 low = (1u << k) - 1u;
-        const u32 chunk = (segs_per_win >> 1) / nsplit;
-        for (u32 t = split * chunk + lt; t < (split + 1) * chunk; t += lb) {
-            u32 s = ((t & ~low) << 1) | (1u << k) | (t & low);
-            Xyzz<KF> v = ld_xyzz<KF>(&runs[(size_t)w * segs_per_win + s]);
-            xyzz_add_inl<KF>(acc, v);
-        }
+    for (u32 t = blk * chunk + lt; t < t_end; t += RED_SUM_LANES) {
+        const u32 j = direct ? t : (((t & ~low) << 1) | (1u << k) | (t & low));  // the t-th j with bit k set
+        Xyzz<KF> v = ld_xyzz<KF>(&src[j]);
+        xyzz_add_inl<KF>(acc, v);
     }
     block_tree_sum<KF>(sm, acc);
-    if (lt == 0) {  // weight of this job inside the window sum: 1 for job 0, 2^(k + RED_SEG_LOG) for T_k
-        Xyzz<KF> v = ld_xyzz<KF>(&sm[0]);
-        const int shift = (job == 0 || nsplit > 1) ? 0 : (int)job - 1 + RED_SEG_LOG;
-        for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
-        st_xyzz<KF>(&out[blockIdx.x], v);
-    }
+    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
 }
 
-// one block per (window, job): tree sum of the job's nsplit pieces (nsplit <= 64), then the job's weight
+// one workgroup per (set, job): tree sum of the job's nblk <= RED_SUM_LANES pieces
 template <class KF>
-__global__ void __launch_bounds__(128) k_reduce_l2b(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ pieces, int nbits,
-                                                    u32 nsplit, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+__global__ void __launch_bounds__(128) k_reduce_fin(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ pieces, u32 nblk,
+                                                    Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 job = blockIdx.x % (u32)(nbits + 1), lt = logical_local<KF>();
-    Xyzz<KF> v = lt < nsplit ? ld_xyzz<KF>(&pieces[(size_t)blockIdx.x * nsplit + lt]) : xyzz_identity<KF>();
+    const u32 lt = logical_local<KF>();
+    Xyzz<KF> v = lt < nblk ? ld_xyzz<KF>(&pieces[(size_t)blockIdx.x * nblk + lt]) : xyzz_identity<KF>();
     block_tree_sum<KF>(sm, v);
-    if (lt == 0) {
-        Xyzz<KF> r = ld_xyzz<KF>(&sm[0]);
-        const int shift = job == 0 ? 0 : (int)job - 1 + RED_SEG_LOG;
-        for (int i = 0; i < shift; i++) r = xyzz_dbl_inl<KF>(r);
-        st_xyzz<KF>(&out[blockIdx.x], r);
-    }
-}
-
-// one block per window: tree sum of the (already weighted) nbits + 1 job results
-constexpr u32 RED_L3_THREADS = 32;
-template <class KF>
-__global__ void __launch_bounds__(64) k_reduce_l3(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ l2, int nbits,
-                                                  Xyzz<typename FieldTraits<KF>::Store>* __restrict__ win_sums) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    typedef typename FieldTraits<KF>::Store S;
-    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 w = blockIdx.x, lt = logical_local<KF>();
-    Xyzz<KF> v = lt <= (u32)nbits ? ld_xyzz<KF>(&l2[(size_t)w * (nbits + 1) + lt]) : xyzz_identity<KF>();
-    block_tree_sum<KF>(sm, v);
-    if (lt == 0) st_xyzz<KF>(&win_sums[w], ld_xyzz<KF>(&sm[0]));
+    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
 }
 
 // ---------------------------------------------------------------------------------------
