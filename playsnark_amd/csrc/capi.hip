@@ -77,6 +77,7 @@ struct ps_ctx {
     bool tail_used = false;
     // MSM workspace
     DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts, coarse;
+    DevBuf affine_tmp;  // XYZZ points + chain products of k_batch_to_affine (fixed-base multiplications, window tables)
     DevBuf staging;                  // byte staging for uploads / downloads
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -220,7 +221,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->tail) (void)hipStreamSynchronize(c->tail);
     for (DevBuf* b : {&c->counts, &c->offs, &c->bsum, &c->keys, &c->ranks, &c->sorted, &c->buckets, &c->parts,
-                      &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->coarse, &c->staging, &c->fb_table[0], &c->fb_table[1]})
+                      &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->coarse, &c->staging, &c->affine_tmp, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
     if (c->g16_pa) ps_points_free(c->g16_pa);
@@ -413,19 +414,40 @@ extern "C" int ps_points_upload(ps_ctx* c, int group, const uint8_t* pts, size_t
     return PS_OK;
 }
 
+// XYZZ -> affine for n points on c->stream (k_batch_to_affine): `tmp` holds the XYZZ points followed by the chain products.
+// (A context buffer, not hipMallocAsync: memory fresh from the stream-ordered pool lost the writes of the first kernel's
+// later workgroups on this runtime -- points 256.. of a 300-point array came back as the identity.)
+// Threads: at least 16 points per inversion, at most 2^16 chains.
+static size_t batch_affine_tmp_bytes(size_t n, size_t xyzz_bytes) { return n * (xyzz_bytes + sizeof(Fp)); }
+template <class F>
+static void batch_to_affine(ps_ctx* c, char* tmp, size_t n, char* out, u32 out_stride) {
+    const u32 T = (u32)std::min<size_t>(65536, std::max<size_t>(1, n / 16));
+    hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(nblocks(T)), dim3(256), 0, c->stream, (const Xyzz<F>*)tmp, (u32)n, T,
+                       (Fp*)(tmp + n * sizeof(Xyzz<F>)), out, out_stride);
+}
+
 template <class F>
 static int fixed_base(ps_ctx* c, int gi, const ps_scalars* k, ps_points* out) {
+    typedef typename KernelField<F>::type KF;
+    constexpr unsigned LN = FieldTraits<KF>::LANES;
     if (!c->fb_ready[gi]) {
         int rc = c->fb_table[gi].ensure(sizeof(Affine<F>) * 32 * 256);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_fixed_base_table<F>, dim3(32), dim3(256), 0, c->stream, (Affine<F>*)c->fb_table[gi].p);
+        if ((rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(32 * 256, sizeof(Xyzz<F>))))) return rc;
+        hipLaunchKernelGGL(k_fixed_base_table<KF>, dim3(32 * LN), dim3(256), 0, c->stream, (Xyzz<F>*)c->affine_tmp.p);
+        batch_to_affine<F>(c, (char*)c->affine_tmp.p, 32 * 256, (char*)c->fb_table[gi].p, (u32)sizeof(Affine<F>));
         HIP_TRY(hipGetLastError());
         c->fb_ready[gi] = true;
     }
-    if (k->n)
-        hipLaunchKernelGGL(k_fixed_base_mul<F>, dim3(nblocks(k->n)), dim3(256), 0, c->stream,
-                           (const Affine<F>*)c->fb_table[gi].p, scalars_ptr(k), (u32)k->n, (Affine<F>*)out->st->p);
-    HIP_TRY(hipGetLastError());
+    if (k->n) {
+        int rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(k->n, sizeof(Xyzz<F>)));
+        if (rc) return rc;
+        char* tmp = (char*)c->affine_tmp.p;
+        hipLaunchKernelGGL(k_fixed_base_mul<KF>, dim3(nblocks(k->n * LN)), dim3(256), 0, c->stream,
+                           (const Affine<F>*)c->fb_table[gi].p, scalars_ptr(k), (u32)k->n, (Xyzz<F>*)tmp);
+        batch_to_affine<F>(c, tmp, k->n, (char*)out->st->p, (u32)sizeof(Affine<F>));
+        HIP_TRY(hipGetLastError());
+    }
     return PS_OK;
 }
 
@@ -526,14 +548,22 @@ static int table_window_for(size_t n) {
 }
 template <class F>
 static int build_table(ps_ctx* c, Storage* st, int group, int wbits, int W) {
+    typedef typename KernelField<F>::type KF;
+    constexpr unsigned LN = FieldTraits<KF>::LANES;
     const size_t n = st->count;
     const u32 rb = (u32)table_row_bytes(group);
     char* tab = (char*)st->table;
-    // row 0: the points themselves (zero doublings), re-laid out in padded rows
-    hipLaunchKernelGGL(k_table_next<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const char*)st->p, (u32)sizeof(Affine<F>), tab, rb, (u32)n, 0);
-    for (int w = 1; w < W; w++)
-        hipLaunchKernelGGL(k_table_next<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const char*)(tab + (size_t)(w - 1) * n * rb), rb,
-                           tab + (size_t)w * n * rb, rb, (u32)n, wbits);
+    hipLaunchKernelGGL(k_table_row0<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<F>*)st->p, tab, rb, (u32)n);
+    if (W > 1) {
+        int rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(n, sizeof(Xyzz<F>)));
+        if (rc) return rc;
+        char* tmp = (char*)c->affine_tmp.p;
+        for (int w = 1; w < W; w++) {
+            hipLaunchKernelGGL(k_table_next<KF>, dim3(nblocks(n * LN)), dim3(256), 0, c->stream, (const char*)(tab + (size_t)(w - 1) * n * rb),
+                               rb, (u32)n, wbits, (Xyzz<F>*)tmp);
+            batch_to_affine<F>(c, tmp, n, tab + (size_t)w * n * rb, rb);
+        }
+    }
     HIP_TRY(hipGetLastError());
     return PS_OK;
 }
@@ -808,7 +838,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
     PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
-    constexpr bool PF = LN == 1;  // G1: next point prefetched; the lane-pair G2 kernel has no registers to spare
+    constexpr bool PF = LN == 1 || PS_G2_ACC_WAVES == 1;  // next point prefetched (the lane-pair G2 kernel at two waves per SIMD has no registers to spare)
     hipLaunchKernelGGL((k_accumulate<KF, PF>), dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, src,
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, idx_mask, w_stride, pstride,
                        (Xyzz<F>*)wc->buckets.p, (Xyzz<F>*)wc->parts.p);

@@ -519,6 +519,12 @@ __host__ __device__ __attribute__((noinline)) Fp fp_mul_call(Fp a, Fp b) { retur
 #else
 PS_HD inline Fp fp_mul_call(Fp a, Fp b) { return f_mul(a, b); }
 #endif
+// ... and of the squaring (three quarters of the multiplier work): the exponentiation loops
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP2_INLINE)
+__host__ __device__ __attribute__((noinline)) Fp fp_sqr_call(Fp a) { return f_sqr(a); }
+#else
+PS_HD inline Fp fp_sqr_call(Fp a) { return f_sqr(a); }
+#endif
 
 // V == 0 (mod p)?  Valid for any lazy value with class <= 8 and |V| <= 16p.
 // Filter: V = k*p with |k| <= 16 forces (V mod 2^28) * p^-1 = k (mod 2^28); computed from limb 0
@@ -639,7 +645,7 @@ PS_HD inline Fp f_inv(const Fp& a) {
     Fp base = a;
     for (int i = 0; i < 381; i++) {
         if ((e[i >> 5] >> (i & 31)) & 1) acc = fp_mul_call(acc, base);
-        base = fp_mul_call(base, base);
+        base = fp_sqr_call(base);
     }
     return acc;
 }
@@ -694,7 +700,7 @@ PS_HD inline Fp fp_pow_words(const Fp& a, const u32* e, int nbits) {
     Fp base = a;
     for (int i = 0; i < nbits; i++) {
         if ((e[i >> 5] >> (i & 31)) & 1) acc = fp_mul_call(acc, base);
-        base = fp_mul_call(base, base);
+        base = fp_sqr_call(base);
     }
     return acc;
 }

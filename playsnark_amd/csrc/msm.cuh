@@ -793,10 +793,14 @@ __device__ inline void next_bucket(const u32* __restrict__ offs, u32 G, u32 p, u
     bend = offs[g + 1];
 }
 
+#ifndef PS_G2_ACC_WAVES
+#define PS_G2_ACC_WAVES 1
+#endif
+#define PS_ACC_WAVES(KF) (FieldTraits<KF>::LANES == 2 ? PS_G2_ACC_WAVES : 2)
 // PREFETCH: the next entry's point is requested before the current addition starts (28 more VGPRs), so that
 // the ~2 us of an HBM gather hide under the ~7 us of the addition even when both waves of a SIMD miss together.
 template <class KF, bool PREFETCH>
-__global__ void __launch_bounds__(256, 2) k_accumulate(const char* __restrict__ points,
+__global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char* __restrict__ points,
                                                        const u32* __restrict__ sorted, const u32* __restrict__ offs,
                                                        u32 G, int M, u32 idx_mask, u64 w_stride, u32 pstride,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
@@ -1352,37 +1356,101 @@ PS_INL Affine<Fp2> generator(const Fp2*) {
 // Fixed-base table: T[j][d] = d * 2^(8j) * G for j = 0..31, d = 0..255 (d = 0 unused).
 // out[i] = sum_j T[j][byte_j(k_i)]: 32 mixed additions per scalar instead of 255 doublings +
 // ~128 additions.  This is the device form of Point.Mul(s, nil) (curve.go:25-31, algebra.go:373).
-template <class F>
-__global__ void __launch_bounds__(256) k_fixed_base_table(Affine<F>* __restrict__ table) {
-    // one thread per (j, d); d*2^(8j)*G by double-and-add on the generator
-    u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+template <class KF>
+__global__ void __launch_bounds__(256, 1) k_fixed_base_table(Xyzz<typename FieldTraits<KF>::Store>* __restrict__ table) {
+    // one logical thread per (j, d); d*2^(8j)*G by double-and-add on the generator, XYZZ out (k_batch_to_affine follows)
+    typedef typename FieldTraits<KF>::Store S;
+    const u32 idx = logical_tid<KF>();
     if (idx >= 32 * 256) return;
-    u32 j = idx >> 8, d = idx & 255;
-    Affine<F> g = generator((const F*)0);
-    Xyzz<F> base = xyzz_from_affine<F>(g.x, g.y);
-    for (u32 i = 0; i < 8 * j; i++) base = xyzz_dbl<F>(base);
-    Xyzz<F> acc = xyzz_mul_small<F>(base, d);
-    Affine<F> out;
-    if (!xyzz_to_affine<F>(acc, out.x, out.y)) { out.x = f_zero((const F*)0); out.y = f_zero((const F*)0); }
-    table[idx] = out;
+    const u32 j = idx >> 8, d = idx & 255;
+    const Affine<S> gs = generator((const S*)0);
+    const Affine<KF> g = ld_affine<KF>(&gs);
+    Xyzz<KF> base = xyzz_from_affine<KF>(g.x, g.y);
+#pragma unroll 1
+    for (u32 i = 0; i < 8 * j; i++) base = xyzz_dbl_inl<KF>(base);
+    Xyzz<KF> acc = xyzz_identity<KF>();
+#pragma unroll 1
+    for (int bit = 7; bit >= 0; bit--) {
+        acc = xyzz_dbl_inl<KF>(acc);
+        if ((d >> bit) & 1) xyzz_add_inl<KF>(acc, base);
+    }
+    st_xyzz<KF>(&table[idx], acc);
 }
 
-// Window table of a resident CRS array: next[i] = 2^c * prev[i] (affine in, affine out).  T[w] = 2^(c w) P lets
-// every window of a sum share ONE bucket set, which is what allows c = 20 (13 digits per 255-bit scalar instead of 16).
+// Window table of a resident CRS array: T[w][i] = 2^(c w) P_i lets every window of a sum share ONE bucket set, which is
+// what allows c = 20 (13 digits per 255-bit scalar instead of 16).  Row 0 is the array itself in padded rows; row w is
+// c doublings of row w - 1 (XYZZ, lane pairs for G2) followed by k_batch_to_affine.
 template <class F>
-__global__ void __launch_bounds__(256) k_table_next(const char* __restrict__ prev, u32 prev_stride, char* __restrict__ next, u32 next_stride,
-                                                    u32 n, int c) {
+__global__ void __launch_bounds__(256) k_table_row0(const Affine<F>* __restrict__ pts, char* __restrict__ row, u32 row_stride, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<F> a = *reinterpret_cast<const Affine<F>*>(prev + (size_t)i * prev_stride);
-    Affine<F> r;
-    r.x = f_zero((const F*)0); r.y = f_zero((const F*)0);
-    if (!(fp_all_zero(a.x) && fp_all_zero(a.y))) {
-        Xyzz<F> t = xyzz_from_affine<F>(a.x, a.y);
-        for (int k = 0; k < c; k++) t = xyzz_dbl<F>(t);
-        if (!xyzz_to_affine<F>(t, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
+    *reinterpret_cast<Affine<F>*>(row + (size_t)i * row_stride) = pts[i];
+}
+template <class KF>
+__global__ void __launch_bounds__(256, 1) k_table_next(const char* __restrict__ prev, u32 prev_stride, u32 n, int c,
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    typedef typename FieldTraits<KF>::Store S;
+    const u32 i = logical_tid<KF>();
+    if (i >= n) return;
+    Affine<KF> a = ld_affine<KF>(reinterpret_cast<const Affine<S>*>(prev + (size_t)i * prev_stride));
+    Xyzz<KF> t = xyzz_identity<KF>();
+    if (!affine_is_identity<KF>(a)) {
+        t = xyzz_from_affine<KF>(a.x, a.y);
+#pragma unroll 1
+        for (int k = 0; k < c; k++) t = xyzz_dbl_inl<KF>(t);
     }
-    *reinterpret_cast<Affine<F>*>(next + (size_t)i * next_stride) = r;
+    st_xyzz<KF>(&out[i], t);
+}
+
+// ---- XYZZ -> affine for whole arrays: ONE field inversion per thread (Montgomery's trick) ----
+// An inversion is a 381-bit exponentiation, ~570 products -- more than the 32 mixed additions of a fixed-base
+// multiplication (320) or the 20 doublings of a table row (180) it used to follow in every thread.  Here thread t owns
+// the points t, t + T, t + 2T, ...: a forward pass leaves the running product of the keys before each point in pre[],
+// one inversion, a backward pass peels the inverses off: 9 products per point plus 570 / (n / T).
+// The key of a point is ZZ * ZZZ for G1 and the norm d0^2 + d1^2 of d = ZZ * ZZZ for G2 (1 / d = conj(d) / norm), so
+// that the chain and the inversion stay in Fp for both groups.  The identity (ZZ = 0) is skipped and stored as (0, 0).
+PS_INL Fp inv_key(const Fp& d) { return d; }
+PS_INL Fp inv_key(const Fp2& d) {
+    const Fp d0 = f_norm(d.c0), d1 = f_norm(d.c1);
+    return f_norm(f_add(fp_mul_call(d0, d0), fp_mul_call(d1, d1)));
+}
+PS_INL Fp inv_from_key(const Fp&, const Fp& kinv) { return kinv; }
+PS_INL Fp2 inv_from_key(const Fp2& d, const Fp& kinv) {
+    return Fp2{fp_mul_call(f_norm(d.c0), kinv), f_neg(fp_mul_call(f_norm(d.c1), kinv))};
+}
+template <class F>
+__global__ void __launch_bounds__(256, 1) k_batch_to_affine(const Xyzz<F>* __restrict__ in, u32 n, u32 T, Fp* __restrict__ pre,
+                                                            char* __restrict__ out, u32 out_stride) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || t >= n) return;
+    Fp run = fp_one();
+    u32 last = t;
+#pragma unroll 1
+    for (u32 i = t; i < n; i += T) {
+        pre[i] = run;
+        const Fp key = inv_key(f_mul(in[i].zz, in[i].zzz));
+        if (!f_is_zero(key)) run = fp_mul_call(run, key);
+        last = i;
+    }
+    Fp inv = f_inv(run);
+#pragma unroll 1
+    for (u32 i = last;; i -= T) {
+        const Xyzz<F> p = in[i];
+        Affine<F> r;
+        r.x = f_zero((const F*)0);
+        r.y = f_zero((const F*)0);
+        const F d = f_mul(p.zz, p.zzz);
+        const Fp key = inv_key(d);
+        if (!f_is_zero(key)) {
+            const Fp kinv = fp_mul_call(inv, pre[i]);
+            inv = fp_mul_call(inv, key);
+            const F dinv = inv_from_key(d, kinv);
+            r.x = fp_canon(f_mul(p.x, f_mul(dinv, p.zzz)));  // stored affine coordinates are always canonical
+            r.y = fp_canon(f_mul(p.y, f_mul(dinv, p.zz)));
+        }
+        *reinterpret_cast<Affine<F>*>(out + (size_t)i * out_stride) = r;
+        if (i == t) break;
+    }
 }
 
 // out[i] = a[i] + b[i] + c[i] (affine in, affine out; (0,0) is the identity)
@@ -1403,24 +1471,24 @@ __global__ void __launch_bounds__(256, 2) k_points_add3(const Affine<F>* __restr
     out[i] = r;
 }
 
-template <class F>
-__global__ void __launch_bounds__(256, 2) k_fixed_base_mul(const Affine<F>* __restrict__ table,
+// out[i] = k_i * G in XYZZ form (k_batch_to_affine follows); lane pairs for G2
+template <class KF>
+__global__ void __launch_bounds__(256, 1) k_fixed_base_mul(const Affine<typename FieldTraits<KF>::Store>* __restrict__ table,
                                                            const u32* __restrict__ scalars, u32 n,
-                                                           Affine<F>* __restrict__ out) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                           Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    const u32 i = logical_tid<KF>();
     if (i >= n) return;
-    Xyzz<F> acc = xyzz_identity<F>();
+    Xyzz<KF> acc = xyzz_identity<KF>();
+#pragma unroll 1
     for (int j = 0; j < 32; j++) {
         u32 limb = scalars[8 * (size_t)i + (j >> 2)];
         u32 d = (limb >> (8 * (j & 3))) & 255u;
         if (d) {
-            Affine<F> t = table[j * 256 + d];
-            xyzz_madd<F>(acc, t.x, t.y);
+            Affine<KF> t = ld_affine<KF>(&table[j * 256 + d]);
+            xyzz_madd<KF>(acc, t.x, t.y);
         }
     }
-    Affine<F> r;
-    if (!xyzz_to_affine<F>(acc, r.x, r.y)) { r.x = f_zero((const F*)0); r.y = f_zero((const F*)0); }
-    out[i] = r;
+    st_xyzz<KF>(&out[i], acc);
 }
 
 }  // namespace ps
