@@ -191,8 +191,8 @@ def launch_ranks(args) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=20, help="weak scaling: points per GPU = 2^log2n")
     ap.add_argument("--total-log2n", type=int, default=0,
                     help="strong scaling: 2^T points in total, sharded by index range over the GPUs (config #4: 24)")
