@@ -91,9 +91,11 @@ PS_COLD Xyzz<F> xyzz_dbl(Xyzz<F> p) {
     return r;
 }
 
-// acc += (x2, y2), affine and not the identity (madd-2008-s): 8M + 2S
+// acc += (x2, y2), affine and not the identity (madd-2008-s): 8M + 2S.  _inl is forced inline for the accumulation
+// kernel: left to the inliner, the lane-pair instance became an out-of-line call (both operands through scratch, the G2
+// sum 8.2 -> 11.2 ms) the day a second kernel started using it.
 template <class F>
-PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
+PS_INL void xyzz_madd_inl(Xyzz<F>& acc, const F& x2, const F& y2) {
     if (xyzz_is_identity(acc)) {
         acc = xyzz_from_affine<F>(x2, y2);
         return;
@@ -117,6 +119,8 @@ PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) {
     acc.x = x3;
     acc.y = y3;
 }
+template <class F>
+PS_HD inline void xyzz_madd(Xyzz<F>& acc, const F& x2, const F& y2) { xyzz_madd_inl<F>(acc, x2, y2); }
 
 // acc += q (add-2008-s): 12M + 2S.  _inl is forced inline for the latency-bound reduction kernels
 // (an out-of-line call passes both 224-byte operands through scratch memory).

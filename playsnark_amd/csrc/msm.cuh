@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char
             }
             if (!affine_is_identity<KF>(pt)) {
                 if (e >> 31) pt.y = f_neg(pt.y);
-                xyzz_madd<KF>(acc, pt.x, pt.y);
+                xyzz_madd_inl<KF>(acc, pt.x, pt.y);
             }
             pt = nxt; e = e1; e1 = e2;
         }
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char
             Affine<KF> pt = ld_entry_point<KF>(points, e, idx_mask, w_stride, pstride);
             if (!affine_is_identity<KF>(pt)) {
                 if (e >> 31) pt.y = f_neg(pt.y);
-                xyzz_madd<KF>(acc, pt.x, pt.y);
+                xyzz_madd_inl<KF>(acc, pt.x, pt.y);
             }
         }
     }
