@@ -1,0 +1,69 @@
+"""The shipped gfx950 code object, read without a GPU: the hot kernels spill nothing and hold their field
+arithmetic inline.  (The lane-pair mixed addition once became an out-of-line call when a second kernel started to
+share it -- every test stayed green and the G2 sum went from 8.2 to 11.2 ms.)"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+LIB = os.path.join(ROOT, "playsnark_amd", "libplaysnark_hip.so")
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    if not (os.path.exists(LIB) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("library or LLVM tools not present")
+    d = tmp_path_factory.mktemp("co")
+    shutil.copy(LIB, d / "lib.so")
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, check=True, capture_output=True)
+    co = [f for f in os.listdir(d) if f.endswith("gfx950")]
+    assert len(co) == 1, os.listdir(d)
+    return str(d / co[0])
+
+
+def kernel_notes(co):
+    out = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    kernels, cur = {}, {}
+    for line in out.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.groups()
+        if key == "agpr_count" and cur.get("name"):
+            kernels[cur["name"]] = cur
+            cur = {}
+        cur[key] = val
+    if cur.get("name"):
+        kernels[cur["name"]] = cur
+    return kernels
+
+
+def test_hot_kernels_do_not_spill(code_object):
+    notes = kernel_notes(code_object)
+    hot = [n for n in notes if re.search(r"k_accumulate|k_reduce_l1|k_reduce_sum|k_fixupI|k_ntt_passILb0|k_table_next|k_fixed_base_mul|k_batch_to_affine", n)]
+    assert len(hot) >= 12, hot
+    for n in hot:
+        assert int(notes[n]["vgpr_spill_count"]) == 0, (n, notes[n])
+
+
+def test_accumulation_kernels_hold_the_mixed_addition_inline(code_object):
+    asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", code_object], check=True, capture_output=True, text=True).stdout
+    bodies = {}
+    name = None
+    for line in asm.splitlines():
+        m = re.match(r"[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            name = m.group(1)
+            bodies[name] = 0
+        elif name and "v_mad_" in line and "64" in line:
+            bodies[name] += 1
+    acc = {n: c for n, c in bodies.items() if "k_accumulate" in n}
+    assert len(acc) == 2, acc
+    for n, c in acc.items():
+        # one mixed addition is 3542 multiply-adds per lane for G1 and 5488 for the lane-pair G2 kernel;
+        # the prefetching loop keeps one copy
+        assert c >= 3500, (n, c)
