@@ -64,7 +64,7 @@ struct DevBuf {
     }
 };
 
-constexpr size_t PS_PINNED_SLOT = 256 * sizeof(Xyzz<Fp2>);  // partial results of one MSM's reduction (sets * jobs <= 256)
+constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>);  // what the host folds: window sums (W <= 64) or one set's partial results (<= 21)
 
 struct ps_ctx {
     int device = 0;
@@ -823,13 +823,13 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
     if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + 5 * (size_t)per_role + (size_t)nres * rp.nblk)))) return rc;
-    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * (size_t)nres))) return rc;
+    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * ((size_t)nres + (size_t)pl.sets)))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
     const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
-    if (sizeof(Xyzz<F>) * (size_t)nres > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
+    if (sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
@@ -874,11 +874,15 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         if (rp.nblk > 1)
             hipLaunchKernelGGL(k_reduce_fin<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
                                (const Xyzz<F>*)pieces, rp.nblk, (Xyzz<F>*)wc->wins.p);
+        if (pl.sets > 1)  // per-set weights on the device; the set sums follow the partial results in `wins`
+            hipLaunchKernelGGL(k_reduce_weights<KF>, dim3((unsigned)pl.sets), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                               (const Xyzz<F>*)wc->wins.p, rp.njobs, (Xyzz<F>*)wc->wins.p + nres);
     }
     PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, wc->wins.p, sizeof(Xyzz<F>) * nres,
-                           hipMemcpyDeviceToHost, st));
+    // one set: its partial results (the host applies the weights); several: the set sums
+    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, (const Xyzz<F>*)wc->wins.p + (pl.sets > 1 ? nres : 0),
+                           sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(wc->ev_tail_done, st));
     wc->tail_used = true;
     return PS_OK;
@@ -918,22 +922,22 @@ static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc
 
 template <class F>
 static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) {
-    // per bucket set the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6):
-    //   set sum = A + 8 * (Q0 + 2 Q1 + 4 Q2 + 8 * sum_k 2^k T_k)
     const Xyzz<F>* res = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
-    const ReducePlan rp = reduce_plan(pl.NB);
     Xyzz<F> acc = xyzz_identity<F>();
-    for (int w = pl.sets - 1; w >= 0; w--) {  // one set (window table): the sum itself
-        const Xyzz<F>* r = res + (size_t)w * rp.njobs;
-        Xyzz<F> s = xyzz_identity<F>();
+    if (pl.sets == 1) {
+        // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
+        const ReducePlan rp = reduce_plan(pl.NB);
         for (int j = (int)rp.njobs - 1; j >= 1; j--) {
-            s = xyzz_dbl<F>(s);
-            xyzz_add<F>(s, r[j]);
+            acc = xyzz_dbl<F>(acc);
+            xyzz_add<F>(acc, res[j]);
         }
-        for (int i = 0; i < RED_SEG_LOG; i++) s = xyzz_dbl<F>(s);
-        xyzz_add<F>(s, r[0]);
-        for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, s);
+        for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<F>(acc);
+        xyzz_add<F>(acc, res[0]);
+    } else {
+        for (int w = pl.sets - 1; w >= 0; w--) {  // Horner over the window sums (k_reduce_weights made them)
+            for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
+            xyzz_add<F>(acc, res[w]);
+        }
     }
     write_affine(out, acc);
 }

@@ -1120,6 +1120,24 @@ __global__ void __launch_bounds__(128) k_reduce_fin(const Xyzz<typename FieldTra
     if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
 }
 
+// Several bucket sets (the plain plan: one per window): the weights 2^(j+2) of a set's partial results are applied here,
+// one workgroup per set -- every lane doubles its own result, then an LDS tree -- because W Horner chains of c - 1
+// doublings each would cost the host's scalar code more (0.4 ms at W = 16) than the 0.15 ms this takes.  With ONE set
+// (window tables) the chain is 19 doublings, 50 us on the host, and the kernel is skipped.
+template <class KF>
+__global__ void __launch_bounds__(128) k_reduce_weights(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ res, u32 njobs,
+                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
+    const u32 lt = logical_local<KF>();
+    Xyzz<KF> v = lt < njobs ? ld_xyzz<KF>(&res[(size_t)blockIdx.x * njobs + lt]) : xyzz_identity<KF>();
+    const int shift = (lt == 0 || lt >= njobs) ? 0 : (int)lt - 1 + RED_SEG_LOG;  // A: 1; job j >= 1: 8 * 2^(j-1)
+    for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
+    block_tree_sum<KF>(sm, v);
+    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
+}
+
 // ---------------------------------------------------------------------------------------
 // auxiliary kernels: format conversion, fixed-base multiplication
 // ---------------------------------------------------------------------------------------
