@@ -233,12 +233,27 @@ def main():
     dist = None
     world = 1
     devices = [local_rank]
+    backend_used = None
     if env_world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend_used = args.backend
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank))
+            try:
+                import datetime
+
+                dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.zeros(1, dtype=torch.uint8, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)  # the communicator is built here, not at init: fail now, on every rank alike
+            except Exception as e:  # RCCL unavailable between these devices: the exchange is 96 bytes per sum, gloo carries it
+                print(f"bench.py rank {rank}: RCCL init failed ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                dist.init_process_group("gloo", rank=rank, world_size=env_world)
+                backend_used = "gloo (RCCL init failed)"
         else:
             dist.init_process_group("gloo", rank=rank, world_size=env_world)
         world = dist.get_world_size()
@@ -379,7 +394,7 @@ def main():
                 "in_flight": args.in_flight,
                 "sharding": "index range per rank, all_gather of %d-B partial sums" % (96 if g == "g1" else 192) if world > 1 else "single GPU",
                 "devices": devices,
-                "backend": (args.backend if world > 1 else None),
+                "backend": (backend_used if world > 1 else None),
             },
             "%s_adds_per_s" % g: adds * world * args.steps / elapsed,
             "stage_ms": stage_ms,

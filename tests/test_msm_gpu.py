@@ -123,16 +123,19 @@ def test_blind_eval_int64_witness_scalars(ps_api, ctx, co, pr, name):
     assert ctx.last_msm_info()["windows"] * ctx.last_msm_info()["window_bits"] < 128
 
 
-@pytest.mark.parametrize("c", [4, 5, 7, 11, 16, 18, 20])
-def test_window_size_does_not_change_the_result(ps_api, ctx, co, pr, c):
-    """Forced window sizes; 18 and 20 give more than 2^20 buckets, which takes the one-level sort with returning
-    atomics (k_digits_grouped / k_scatter) instead of the two-level counting sort."""
+@pytest.mark.parametrize("c,group", [(c, "G1") for c in (4, 5, 6, 7, 8, 9, 11, 13, 16, 18, 20)] + [(c, "G2") for c in (4, 7, 10, 16, 19)])
+def test_window_size_does_not_change_the_result(ps_api, ctx, co, pr, c, group):
+    """Forced window sizes; 18 and up give more than 2^20 buckets, which takes the one-level sort with returning
+    atomics (k_digits_grouped / k_scatter) instead of the two-level counting sort.  The sizes also walk the shapes of the
+    bucket reduction: fewer than 8 segments per set (c <= 6), one group of segments (7), bit jobs (8 and up), several
+    workgroups per job and k_reduce_fin (18 and up)."""
     rng = _rng(pr, 11)
-    n = 777
+    n = 777 if group == "G1" else 200
+    og = getattr(co, group)
     sc = [rng.fr() for _ in range(n)]
-    raw = co.G1.gen_points(rng.fr(), rng.fr(), n)
-    pts = ps_api.Points.upload(ctx, ps_api.G1, raw)
-    want = co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(sc), raw, n, 4))
+    raw = og.gen_points(rng.fr(), rng.fr(), n)
+    pts = ps_api.Points.upload(ctx, getattr(ps_api, group), raw)
+    want = og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4))
     try:
         ctx.set_window(c)
         assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want
