@@ -293,6 +293,26 @@ static void test_pairing() {
     CHECK(pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P210), Q1}}), "e(6P, 35Q) != e(210P, Q)");
     CHECK(!pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P211), Q1}}), "e(6P, 35Q) == e(211P, Q)");
     std::printf("pairing bilinearity ok\n");
+    // the fast path against the literal one: the projective Miller loop differs from the affine one only by factors in
+    // proper subfields (gone after the exponentiation), and final_exp is the cube of the plain (p^12 - 1) / r power
+    using namespace pairing;
+    const unsigned ks[3][2] = {{6, 35}, {1, 1}, {1234567, 89}};
+    for (auto& k : ks) {
+        Affine<Fp> A = small_multiple<Fp>(k[0]);
+        Affine<Fp2> B = small_multiple<Fp2>(k[1]);
+        Fp12 slow = final_exp_generic(miller_affine(A, B));
+        Fp12 mid = final_exp_generic(miller(A, B));
+        CHECK(f12_eq(slow, mid), "projective Miller loop != affine Miller loop after the exponentiation (%u, %u)", k[0], k[1]);
+        Fp12 fast = final_exp(miller(A, B));
+        CHECK(f12_eq(fast, f12_mul(slow, f12_mul(slow, slow))), "final_exp != (plain final exponentiation)^3 (%u, %u)", k[0], k[1]);
+        CHECK(!f12_eq(fast, f12_one()), "degenerate pairing value");
+    }
+    // Frobenius: twelve applications are the identity, and f12_sqr agrees with the product
+    Fp12 f = miller(P, Q35), g = f;
+    for (int i = 0; i < 12; i++) g = f12_frob(g);
+    CHECK(f12_eq(f, g), "frobenius^12 is not the identity");
+    CHECK(f12_eq(f12_sqr(f), f12_mul(f, f)), "f12_sqr != f * f");
+    std::printf("fast pairing path == literal path\n");
 }
 
 int main() {
