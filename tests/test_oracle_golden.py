@@ -137,3 +137,16 @@ def test_fast_quotient_is_the_literal_algorithm(co, pr, n):
     yC[n // 2] = (yC[n // 2] + 1) % pr.R
     with pytest.raises(ArithmeticError):
         co.fast_quotient(yA, yB, yC)
+
+
+def test_final_exponentiation_chain_identity():
+    """The x-chain of the host pairing's final exponentiation (csrc/pairing_math.inc::final_exp) rests on
+    3 (p^4 - p^2 + 1) / r = (x - 1)^2 (x + p)(x^2 + p^2 - 1) + 3 for the BLS12-381 parameter x (Hayashida, Hayasaka,
+    Teruya 2020), and on w^(p-1) = xi^((p-1)/6) needing 6 | p - 1; 3 is prime to r, so the cube decides "== 1" alike."""
+    from oracle import pyref as pr
+
+    p, r = pr.P, pr.R
+    x = -0xD201000000010000
+    assert (p**4 - p**2 + 1) % r == 0 and (p - 1) % 6 == 0 and r % 3 != 0
+    assert 3 * ((p**4 - p**2 + 1) // r) == (x - 1) ** 2 * (x + p) * (x * x + p * p - 1) + 3
+    assert (p**12 - 1) == (p**6 - 1) * (p**2 + 1) * (p**4 - p**2 + 1)

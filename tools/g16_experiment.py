@@ -31,3 +31,10 @@ ts = []
 for _ in range(int(os.environ.get("REPS", "5"))):
     t0 = time.perf_counter(); api.Groth16Prove(tr, q, dsol, r, s); ts.append((time.perf_counter() - t0) * 1e3)
 print(os.environ.get("TAG", ""), "groth16 ms", [round(t, 2) for t in ts], {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()})
+proof = api.Groth16Prove(tr, q, dsol, r, s)
+diff = 1 if os.environ.get("CIRCUIT") == "bits" else 3
+io = api.Poly.upload(ctx, sol[:diff]) if os.environ.get("CIRCUIT") != "bits" else api.Poly.from_values(ctx, sol[:diff])
+tv = []
+for _ in range(3):
+    t0 = time.perf_counter(); ok = api.Groth16Verify(ctx, tr.Alpha, tr.Beta2, vk["Gamma"], tr.Delta2, vk["IoLP"], proof, io); tv.append((time.perf_counter() - t0) * 1e3)
+print("groth16 verify", ok, "ms", [round(t, 1) for t in tv])

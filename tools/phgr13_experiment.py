@@ -18,3 +18,11 @@ ts = []
 for _ in range(int(os.environ.get("REPS", "5"))):
     t0 = time.perf_counter(); api.PHGR13Prove(ek, q, dsol); ts.append((time.perf_counter() - t0) * 1e3)
 print(os.environ.get("TAG", ""), "phgr13 ms", [round(t, 2) for t in ts], {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()})
+proof = api.PHGR13Prove(ek, q, dsol)
+diff = 3  # nbVars - nbIO: const, x, out
+io = api.Poly.upload(ctx, sol[:diff])
+args = (vk.vs.slice(0, diff), vk.ws.slice(0, diff), vk.ys.slice(0, diff))
+tv = []
+for _ in range(3):
+    t0 = time.perf_counter(); ok = api.PHGR13Verify(ctx, vk.fixed_points(), *args, proof, io); tv.append((time.perf_counter() - t0) * 1e3)
+print("phgr13 verify", ok, "ms", [round(t, 1) for t in tv])
