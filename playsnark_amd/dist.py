@@ -26,8 +26,11 @@ class ShardedMsm:
     def __init__(self, ctx, group: int, dist=None, world: int = 1):
         self.ctx, self.group, self.dist, self.world = ctx, group, dist, world
 
-    def combine(self, partial: bytes) -> bytes:
-        """all_gather the per-rank partial sums and fold them (every rank gets the result)."""
+    def combine_start(self, partial: bytes):
+        """Start the all_gather of the per-rank partial sums; combine_finish folds them.  The two halves let the pipelined
+        runner keep the exchange of sum i in flight while sums i+1.. are folded: on the GPU box the RCCL kernel of a
+        96-byte all_gather has to find a free CU among saturated ones, and a blocking collective per step would put that
+        wait (milliseconds under load) on every step's critical path."""
         if self.dist is None or self.world == 1:
             return partial
         import torch
@@ -37,8 +40,19 @@ class ShardedMsm:
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8).to(dev)
         gathered = torch.empty(self.world * nb, dtype=torch.uint8, device=dev)
-        self.dist.all_gather_into_tensor(gathered, mine)
+        work = self.dist.all_gather_into_tensor(gathered, mine, async_op=True)
+        return (work, gathered, mine)
+
+    def combine_finish(self, started) -> bytes:
+        if isinstance(started, (bytes, bytearray)):
+            return bytes(started)
+        work, gathered, _mine = started
+        work.wait()
         return api.points_sum(self.group, gathered.cpu().numpy().tobytes())
+
+    def combine(self, partial: bytes) -> bytes:
+        """all_gather the per-rank partial sums and fold them (every rank gets the result)."""
+        return self.combine_finish(self.combine_start(partial))
 
     def run(self, points: "api.Points", scalars: "api.Poly") -> bytes:
         """Local MSM over this rank's shard, then the exchange."""
@@ -48,17 +62,23 @@ class ShardedMsm:
     def run_pipelined(self, points: "api.Points", scalars: "api.Poly", steps: int, on_step=None, depth: int = 2) -> bytes:
         """`steps` sums with up to `depth` in flight (ps_msm_launch ... / ps_msm_finish FIFO): later sums
         are enqueued before the oldest is folded and exchanged, so their sort and accumulation run
-        beside its latency-bound tail.  Every sum is completed and combined; returns the last result."""
+        beside its latency-bound tail; the exchange of a sum is started when its local result is folded and collected
+        `depth` sums later.  Every sum is completed and combined; returns the last result."""
         result = None
         launched = finished = 0
+        exchanges = []
         while finished < steps:
             while launched < steps and launched - finished < depth:
                 api.msm_launch(self.ctx, points, scalars)
                 launched += 1
-            result = self.combine(api.msm_finish(self.ctx, self.group))
+            exchanges.append(self.combine_start(api.msm_finish(self.ctx, self.group)))
             finished += 1
+            if len(exchanges) > depth:
+                result = self.combine_finish(exchanges.pop(0))
             if on_step:
                 on_step()
+        while exchanges:
+            result = self.combine_finish(exchanges.pop(0))
         return result
 
 

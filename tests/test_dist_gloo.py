@@ -27,6 +27,25 @@ for grp, gid in ((co.G1, api.G1), (co.G2, api.G2)):
     total = ShardedMsm(None, gid, dist, world).combine(partial)
     want = grp.to_b(grp.msm_pippenger(co.pack_fr(sc), raw, n, 2))
     assert total == want, (rank, grp.name)
+# the pipelined runner starts the exchange of sum i and collects it `depth` sums later (async all_gather): the local
+# MSMs come from the oracle here, a different one per step, and every step's folded result must be that step's total
+import playsnark_amd.api as api_mod
+for depth in (1, 3):
+    steps, launched, seen = 5, [], []
+    raw = co.G1.gen_points(9, 11, n)
+    vectors = [[rng.fr() for _ in range(n)] for _ in range(steps)]
+    first, cnt = shard_range(n, rank, world)
+    api_mod.msm_launch = lambda ctx, pts, sc: launched.append(len(launched))
+    def finish(ctx, group, _state={"k": 0}):
+        k = _state["k"] %% steps; _state["k"] += 1
+        return co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(vectors[k][first:first + cnt]), raw[first * 96:(first + cnt) * 96], cnt, 1))
+    api_mod.msm_finish = finish
+    sm = ShardedMsm(None, api.G1, dist, world)
+    orig_finish = sm.combine_finish
+    sm.combine_finish = lambda started: seen.append(orig_finish(started)) or seen[-1]
+    last = sm.run_pipelined(None, None, steps, depth=depth)
+    want = [co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(v), raw, n, 2)) for v in vectors]
+    assert seen == want and last == want[-1] and len(launched) == steps, (rank, depth)
 covered = sorted(sum((list(range(*(lambda f, c: (f, f + c))(*shard_range(10, r, 3)))) for r in range(3)), []))
 assert covered == list(range(10))
 dist.destroy_process_group()
