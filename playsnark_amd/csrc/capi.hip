@@ -15,6 +15,9 @@
 #include "msm.cuh"
 #include "quotient.cuh"
 
+namespace ps {
+#include "hostfield.inc"
+}
 using namespace ps;
 
 // ---------------------------------------------------------------------------------------
@@ -651,6 +654,33 @@ static void write_affine(uint8_t* out, const Xyzz<Fp2>& acc) {
     fp_to_be48_host(out + 96, y.c1);
     fp_to_be48_host(out + 144, y.c0);
 }
+// the same for sums formed in the host representation (hostfield.inc)
+static void write_affine(uint8_t* out, const Xyzz<Fq>& acc) {
+    Fq x, y;
+    if (!xyzz_to_affine<Fq>(acc, x, y)) { memset(out, 0, 96); out[0] = 0x40; return; }
+    fq_to_be48(out, x);
+    fq_to_be48(out + 48, y);
+}
+static void write_affine(uint8_t* out, const Xyzz<Fq2>& acc) {
+    Fq2 x, y;
+    if (!xyzz_to_affine<Fq2>(acc, x, y)) { memset(out, 0, 192); out[0] = 0x40; return; }
+    fq_to_be48(out, x.c1);
+    fq_to_be48(out + 48, x.c0);
+    fq_to_be48(out + 96, y.c1);
+    fq_to_be48(out + 144, y.c0);
+}
+template <class F>
+static Xyzz<typename HostField<F>::type> xyzz_to_host(const Xyzz<F>& p) {
+    Xyzz<typename HostField<F>::type> r;
+    r.x = to_host(p.x); r.y = to_host(p.y); r.zz = to_host(p.zz); r.zzz = to_host(p.zzz);
+    return r;
+}
+template <class F>
+static Affine<typename HostField<F>::type> affine_to_host(const Affine<F>& a) {
+    Affine<typename HostField<F>::type> r;
+    r.x = to_host(a.x); r.y = to_host(a.y);
+    return r;
+}
 static bool is_identity_encoding(const uint8_t* p, size_t wb) {  // 0x40 followed by zeros, nothing else
     if (p[0] != 0x40) return false;
     for (size_t i = 1; i < wb; i++)
@@ -674,11 +704,12 @@ static bool read_affine(Affine<Fp2>& a, const uint8_t* p) {
 
 template <class F>
 static int points_sum_t(const uint8_t* pts, size_t k, uint8_t* out, size_t wb) {
-    Xyzz<F> acc = xyzz_identity<F>();
+    typedef typename HostField<F>::type H;
+    Xyzz<H> acc = xyzz_identity<H>();
     for (size_t i = 0; i < k; i++) {
         Affine<F> a;
         if (!read_affine(a, pts + wb * i)) return fail(PS_ERR_ENCODING, "ps_points_sum: bad point encoding");
-        if (!affine_is_identity<F>(a)) xyzz_madd<F>(acc, a.x, a.y);
+        if (!affine_is_identity<F>(a)) { Affine<H> h = affine_to_host<F>(a); xyzz_madd<H>(acc, h.x, h.y); }
     }
     write_affine(out, acc);
     return PS_OK;
@@ -922,21 +953,22 @@ static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc
 
 template <class F>
 static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) {
+    typedef typename HostField<F>::type H;  // six 64-bit words: the chain below costs the CPU 0.05 ms instead of 0.35
     const Xyzz<F>* res = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
-    Xyzz<F> acc = xyzz_identity<F>();
+    Xyzz<H> acc = xyzz_identity<H>();
     if (pl.sets == 1) {
         // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
         const ReducePlan rp = reduce_plan(pl.NB);
         for (int j = (int)rp.njobs - 1; j >= 1; j--) {
-            acc = xyzz_dbl<F>(acc);
-            xyzz_add<F>(acc, res[j]);
+            acc = xyzz_dbl<H>(acc);
+            xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
         }
-        for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<F>(acc);
-        xyzz_add<F>(acc, res[0]);
+        for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<H>(acc);
+        xyzz_add<H>(acc, xyzz_to_host<F>(res[0]));
     } else {
         for (int w = pl.sets - 1; w >= 0; w--) {  // Horner over the window sums (k_reduce_weights made them)
-            for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<F>(acc);
-            xyzz_add<F>(acc, res[w]);
+            for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<H>(acc);
+            xyzz_add<H>(acc, xyzz_to_host<F>(res[w]));
         }
     }
     write_affine(out, acc);

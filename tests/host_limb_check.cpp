@@ -27,7 +27,16 @@ using namespace ps;
 
 // what pairing_math.inc expects from msm.cuh / capi.hip
 template <class F> static bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }
+namespace ps {
+#include "../playsnark_amd/csrc/hostfield.inc"
+}
+#define PS_HOSTFIELD 1
 #include "../playsnark_amd/csrc/pairing_math.inc"
+template <class F> static Affine<typename HostField<F>::type> affine_to_host(const Affine<F>& a) {
+    Affine<typename HostField<F>::type> r;
+    r.x = to_host(a.x); r.y = to_host(a.y);
+    return r;
+}
 
 static unsigned long long rng_state = 0x706c6179736e6172ull;
 static unsigned long long rnd() {  // splitmix64
@@ -285,34 +294,77 @@ static void test_group_law(const char* name) {
     std::printf("%s group law ok (stored coordinates at limb class <= %d over %d mixed additions)\n", name, worst_cls, K);
 }
 
-static void test_pairing() {
-    // e(aP, bQ) == e(abP, Q) and != e((ab + 1)P, Q): the Miller loop carries its point without a multiplication between
-    // steps (canon_wide), the tower products nest lazy values three levels deep
-    Affine<Fp> P = small_multiple<Fp>(6), P210 = small_multiple<Fp>(210), P211 = small_multiple<Fp>(211);
-    Affine<Fp2> Q35 = small_multiple<Fp2>(35), Q1 = small_multiple<Fp2>(1);
-    CHECK(pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P210), Q1}}), "e(6P, 35Q) != e(210P, Q)");
-    CHECK(!pairing::pairing_product_is_one({{P, Q35}, {pairing::neg_g1(P211), Q1}}), "e(6P, 35Q) == e(211P, Q)");
-    std::printf("pairing bilinearity ok\n");
-    // the fast path against the literal one: the projective Miller loop differs from the affine one only by factors in
-    // proper subfields (gone after the exponentiation), and final_exp is the cube of the plain (p^12 - 1) / r power
-    using namespace pairing;
-    const unsigned ks[3][2] = {{6, 35}, {1, 1}, {1234567, 89}};
-    for (auto& k : ks) {
-        Affine<Fp> A = small_multiple<Fp>(k[0]);
-        Affine<Fp2> B = small_multiple<Fp2>(k[1]);
-        Fp12 slow = final_exp_generic(miller_affine(A, B));
-        Fp12 mid = final_exp_generic(miller(A, B));
-        CHECK(f12_eq(slow, mid), "projective Miller loop != affine Miller loop after the exponentiation (%u, %u)", k[0], k[1]);
-        Fp12 fast = final_exp(miller(A, B));
-        CHECK(f12_eq(fast, f12_mul(slow, f12_mul(slow, slow))), "final_exp != (plain final exponentiation)^3 (%u, %u)", k[0], k[1]);
-        CHECK(!f12_eq(fast, f12_one()), "degenerate pairing value");
+// The pairing over one representation: NS = pairing_dev (Fp / Fp2, the lazy limbs) or pairing (Fq / Fq2, what the
+// verifiers run); CONV brings the device-representation test points into it.
+#define PAIRING_TESTS(NAME, NS, CONV1, CONV2, LABEL)                                                                              \
+    static void NAME() {                                                                                                          \
+        /* e(aP, bQ) == e(abP, Q) and != e((ab + 1)P, Q) */                                                                       \
+        auto P = CONV1(small_multiple<Fp>(6)), P210 = CONV1(small_multiple<Fp>(210)), P211 = CONV1(small_multiple<Fp>(211));      \
+        auto Q35 = CONV2(small_multiple<Fp2>(35)), Q1 = CONV2(small_multiple<Fp2>(1));                                            \
+        CHECK(NS::pairing_product_is_one({{P, Q35}, {NS::neg_g1(P210), Q1}}), LABEL ": e(6P, 35Q) != e(210P, Q)");                \
+        CHECK(!NS::pairing_product_is_one({{P, Q35}, {NS::neg_g1(P211), Q1}}), LABEL ": e(6P, 35Q) == e(211P, Q)");               \
+        /* the fast path against the literal one: the projective Miller loop differs from the affine one only by factors in  */  \
+        /* proper subfields (gone after the exponentiation), and final_exp is the cube of the plain (p^12 - 1) / r power      */  \
+        const unsigned ks[3][2] = {{6, 35}, {1, 1}, {1234567, 89}};                                                               \
+        for (auto& k : ks) {                                                                                                      \
+            auto A = CONV1(small_multiple<Fp>(k[0]));                                                                             \
+            auto B = CONV2(small_multiple<Fp2>(k[1]));                                                                            \
+            NS::Fp12 slow = NS::final_exp_generic(NS::miller_affine(A, B));                                                       \
+            NS::Fp12 mid = NS::final_exp_generic(NS::miller(A, B));                                                               \
+            CHECK(NS::f12_eq(slow, mid), LABEL ": projective Miller loop != affine Miller loop after the exponentiation");        \
+            NS::Fp12 fast = NS::final_exp(NS::miller(A, B));                                                                      \
+            CHECK(NS::f12_eq(fast, NS::f12_mul(slow, NS::f12_mul(slow, slow))), LABEL ": final_exp != (plain exponentiation)^3"); \
+            CHECK(!NS::f12_eq(fast, NS::f12_one()), LABEL ": degenerate pairing value");                                          \
+        }                                                                                                                         \
+        /* Frobenius: twelve applications are the identity, and f12_sqr agrees with the product */                                \
+        NS::Fp12 f = NS::miller(P, Q35), g = f;                                                                                   \
+        for (int i = 0; i < 12; i++) g = NS::f12_frob(g);                                                                         \
+        CHECK(NS::f12_eq(f, g), LABEL ": frobenius^12 is not the identity");                                                      \
+        CHECK(NS::f12_eq(NS::f12_sqr(f), NS::f12_mul(f, f)), LABEL ": f12_sqr != f * f");                                         \
+        std::printf(LABEL ": pairing bilinearity ok, fast pairing path == literal path\n");                                       \
     }
-    // Frobenius: twelve applications are the identity, and f12_sqr agrees with the product
-    Fp12 f = miller(P, Q35), g = f;
-    for (int i = 0; i < 12; i++) g = f12_frob(g);
-    CHECK(f12_eq(f, g), "frobenius^12 is not the identity");
-    CHECK(f12_eq(f12_sqr(f), f12_mul(f, f)), "f12_sqr != f * f");
-    std::printf("fast pairing path == literal path\n");
+#define IDENT(x) (x)
+PAIRING_TESTS(test_pairing_dev, pairing_dev, IDENT, IDENT, "device representation")
+PAIRING_TESTS(test_pairing_host, pairing, affine_to_host<Fp>, affine_to_host<Fp2>, "host field")
+
+// hostfield.inc against field.cuh: conversions round-trip, every operation commutes with them, and the group law gives
+// the same points in both representations
+static void test_host_field() {
+    for (int it = 0; it < 2000; it++) {
+        Fp a = random_lazy(1 + it % 3), b = random_lazy(1 + (it / 3) % 2);  // any lazy value: to_host reduces first
+        Fq ha = to_host(a), hb = to_host(b);
+        CHECK(same_residue(to_device(ha), a), "to_device(to_host(a)) != a");
+        Fp an = f_norm(a), bn = f_norm(b);
+        CHECK(f_eq(to_host(f_mul(an, bn)), f_mul(ha, hb)), "host product != device product");
+        CHECK(f_eq(to_host(f_norm(f_add(a, b))), f_add(ha, hb)), "host sum != device sum");
+        CHECK(f_eq(to_host(f_norm(f_sub(a, b))), f_sub(ha, hb)), "host difference != device difference");
+        CHECK(f_eq(to_host(f_norm(f_neg(a))), f_neg(ha)), "host negation != device negation");
+        if (it < 20 && !f_is_zero(ha)) CHECK(f_eq(f_mul(f_inv(ha), ha), f_one((const Fq*)0)), "host inverse");
+        Fp2 x = Fp2{an, bn}, y = Fp2{bn, f_norm(f_add(an, bn))};
+        CHECK(f_eq(to_host(f_mul(x, y)), f_mul(to_host(x), to_host(y))), "host Fq2 product != device Fp2 product");
+        CHECK(f_eq(to_host(f_sqr(x)), f_sqr(to_host(x))), "host Fq2 square != device Fp2 square");
+    }
+    CHECK(f_is_zero(to_host(fp_zero())) && f_eq(to_host(fp_one()), f_one((const Fq*)0)), "zero / one");
+    uint8_t b1[48], b2[48];
+    Fp g = gen_of((const Fp*)0).x;
+    fp_to_be48(b1, g);
+    fq_to_be48(b2, to_host(g));
+    CHECK(!memcmp(b1, b2, 48), "wire bytes differ between the representations");
+    // [k]G in both representations
+    u32 kw[8] = {0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u, 0x13579bdfu, 0x2468ace0u, 0x0badf00du, 0x0000beefu};
+    Affine<Fp> g1 = gen_of((const Fp*)0);
+    Affine<Fp2> g2 = gen_of((const Fp2*)0);
+    Fp dx, dy; Fq hx, hy;
+    bool ok1 = xyzz_to_affine<Fp>(xyzz_mul_scalar<Fp>(xyzz_from_affine<Fp>(g1.x, g1.y), kw), dx, dy);
+    Affine<Fq> hg1 = affine_to_host<Fp>(g1);
+    bool ok2 = xyzz_to_affine<Fq>(xyzz_mul_scalar<Fq>(xyzz_from_affine<Fq>(hg1.x, hg1.y), kw), hx, hy);
+    CHECK(ok1 && ok2 && f_eq(to_host(dx), hx) && f_eq(to_host(dy), hy), "[k]G differs between the representations (G1)");
+    Fp2 ex, ey; Fq2 kx, ky;
+    ok1 = xyzz_to_affine<Fp2>(xyzz_mul_scalar<Fp2>(xyzz_from_affine<Fp2>(g2.x, g2.y), kw), ex, ey);
+    Affine<Fq2> hg2 = affine_to_host<Fp2>(g2);
+    ok2 = xyzz_to_affine<Fq2>(xyzz_mul_scalar<Fq2>(xyzz_from_affine<Fq2>(hg2.x, hg2.y), kw), kx, ky);
+    CHECK(ok1 && ok2 && f_eq(to_host(ex), kx) && f_eq(to_host(ey), ky), "[k]G differs between the representations (G2)");
+    std::printf("host field == device field\n");
 }
 
 int main() {
@@ -320,7 +372,9 @@ int main() {
     test_fr_and_butterflies();
     test_group_law<Fp>("G1");
     test_group_law<Fp2>("G2");
-    test_pairing();
+    test_host_field();
+    test_pairing_dev();
+    test_pairing_host();
     if (failures) { std::fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
     std::printf("host_limb_check ok\n");
     return 0;

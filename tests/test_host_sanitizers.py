@@ -23,7 +23,7 @@ def test_limb_contract_under_asan_and_ubsan(tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-3000:]
-    for line in ("fp products", "NTT butterfly sequences ok", "G1 group law ok", "G2 group law ok", "pairing bilinearity ok", "fast pairing path == literal path", "host_limb_check ok"):
+    for line in ("fp products", "NTT butterfly sequences ok", "G1 group law ok", "G2 group law ok", "host field == device field", "device representation: pairing bilinearity ok, fast pairing path == literal path", "host field: pairing bilinearity ok, fast pairing path == literal path", "host_limb_check ok"):
         assert line in run.stdout
 
 
