@@ -65,6 +65,29 @@ def test_host_fold_of_partial_sums(co):
         api.points_sum(api.G1, co.G1.to_b(p)[:48] + (neg[1] | 1 << 380).to_bytes(48, "big"))
 
 
+def test_host_fold_in_both_groups_and_lincomb(co, pr):
+    """The host field (csrc/hostfield.inc) behind ps_points_sum / ps_points_lincomb: G1 and G2, the identity among the
+    terms, P + P and P + (-P), scalars 0 and r - 1 -- against the oracle."""
+    from playsnark_amd import api
+
+    rng = pr.SplitMix64(2024)
+    for grp, gid in ((co.G1, api.G1), (co.G2, api.G2)):
+        ks0 = [rng.fr() for _ in range(5)]
+        pts = [grp.mul(k) for k in ks0] + [None]
+        raw = b"".join(grp.to_b(p) for p in pts)
+        want = None
+        for p in pts:
+            want = grp.add(want, p)
+        assert api.points_sum(gid, raw) == grp.to_b(want)
+        p, neg_p = pts[0], grp.mul(pr.R - ks0[0])
+        assert api.points_sum(gid, grp.to_b(p) + grp.to_b(neg_p)) == grp.to_b(None)
+        assert api.points_sum(gid, grp.to_b(p) + grp.to_b(p)) == grp.to_b(grp.add(p, p))
+        ks = [rng.fr() for _ in range(6)]
+        ks[2], ks[3] = 0, pr.R - 1
+        total = sum(k0 * k for k0, k in zip(ks0, ks)) % pr.R
+        assert api.points_lincomb(gid, raw, ks) == grp.to_b(grp.mul(total))
+
+
 def test_point_convert_matches_zcash_encoding(co, pr):
     """Host-side conversion between the uncompressed and compressed ZCash forms (the form kyber's
     MarshalBinary emits, pinochio.go:258-272): against the oracle / the Python twin, G1 and G2,
