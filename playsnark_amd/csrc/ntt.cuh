@@ -45,8 +45,12 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
     tw[i] = acc;
 }
 
-constexpr int NTT_MAX_K = 10;       // butterfly stages per pass (a tile then keeps >= 2 contiguous columns = 80 B runs)
-constexpr int NTT_TILE_LOG = 11;    // 2048 Fr = 80 KB of LDS per workgroup
+// Tile size, measured on the quotient at n = 2^20 (Groth16 route / values route): 2048 elements (80 KB, two 512-thread
+// workgroups per CU, transforms of 2^20 in two passes) 11.3 / 2.9 ms; 1024 elements (40 KB, four 256-thread workgroups per
+// CU, three passes) 10.6-10.9 / 2.65-2.7 ms; 512 elements 10.9 / 2.7 ms.  The passes are bound by their instruction count,
+// not by HBM, so the extra pass costs less than the finer interleaving of load, butterfly and store phases gains.
+constexpr int NTT_MAX_K = 9;        // butterfly stages per pass (a tile then keeps >= 2 contiguous columns = 80 B runs)
+constexpr int NTT_TILE_LOG = 10;    // 1024 Fr = 40 KB of LDS per workgroup
 
 // One pass over transforms of 2^p points: k stages with half-distances D*2^m, m = k-1..0 for the
 // forward transform and 0..k-1 for the inverse.  Column q = (hi, lo) with lo = q mod D; element
@@ -75,8 +79,8 @@ struct NttFuse {
     u64 top = 0;                  // REV_PAD / REV_TAKE: index that maps to 0
 };
 
-// __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Two 512-thread workgroups
-// per CU need 4 waves per SIMD, i.e. at most 128 VGPRs; with "2" the inverse pass took 139 and ran one workgroup per CU
+// __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Four 256-thread workgroups
+// per CU (two of 512 with the 80 KB tile) need 4 waves per SIMD, i.e. at most 128 VGPRs; with "2" the inverse pass took 139 and ran one workgroup per CU
 // (measured: no difference in the quotient's time either way -- the passes are bound by their instruction count).
 template <bool INV>
 __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
@@ -257,8 +261,8 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     if (p > tb.log_tab) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
     // a transform that fits one tile runs all its stages in one pass (contiguous in HBM: no stride to respect);
-    // longer ones are cut into passes of at most NTT_MAX_K stages: fewer, longer passes win as long as a
-    // tile keeps a couple of contiguous columns (measured at 2^20: 8 stages 12.25 ms, 9: 11.9, 10: 11.9)
+    // longer ones are cut into passes of at most NTT_MAX_K stages (with the 80 KB tile of round 1, measured at 2^20:
+    // 8 stages 12.25 ms, 9: 11.9, 10: 11.9; see the note at NTT_TILE_LOG for the tile size)
     int npass = p <= NTT_TILE_LOG ? 1 : (p + NTT_MAX_K - 1) / NTT_MAX_K;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
     int done = 0, unscaled = 0;  // unscaled: inverse stages whose factor 2 per stage has not been divided out yet
@@ -271,7 +275,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         u64 cols_total = total >> k;
         unsigned grid = (unsigned)(cols_total >> logCols);
         size_t smem = ((size_t)sizeof(Fr) << k) << logCols;
-        // one four-row group per thread and double stage; two 512-thread workgroups share a CU (2 x 80 KB
+        // one four-row group per thread and double stage; four 256-thread workgroups share a CU (4 x 40 KB
         // of LDS), so 4 waves per SIMD hide the LDS and multiplier latency
         unsigned threads = (unsigned)std::min<u64>(512, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 2));
         NttFuse fz;  // the load belongs to the first pass, the store to the last
