@@ -793,8 +793,12 @@ __device__ inline void next_bucket(const u32* __restrict__ offs, u32 G, u32 p, u
     bend = offs[g + 1];
 }
 
+// Waves per SIMD of the G2 (lane-pair) accumulation.  2: 256 VGPRs, 46 of the kernel's ~300 live registers spilled to
+// scratch, no prefetch; 1: 256 VGPRs + 69 AGPRs, nothing spilled, next point prefetched.  A/B on one box (tools/ab_libs.sh):
+// a lone G2 sum 8.9 vs 8.8 ms, three in flight 7.97 vs 8.17, PHGR13Prove 29.1 vs 30.7 -- a 300-register wave leaves no room
+// on its SIMD for the waves of the other sums' tails, so wherever the kernel shares the chip the spilling variant wins.
 #ifndef PS_G2_ACC_WAVES
-#define PS_G2_ACC_WAVES 1
+#define PS_G2_ACC_WAVES 2
 #endif
 #define PS_ACC_WAVES(KF) (FieldTraits<KF>::LANES == 2 ? PS_G2_ACC_WAVES : 2)
 // PREFETCH: the next entry's point is requested before the current addition starts (28 more VGPRs), so that
@@ -1008,7 +1012,10 @@ constexpr int RED_SEG_LOG = 3;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
 constexpr int RED_DIRECT_JOBS = 4;   // A, Q0, Q1, Q2
 constexpr u32 RED_SUM_LANES = 64;    // logical threads of a SUM / FIN workgroup
-constexpr u32 RED_SUM_TERMS = 512;   // terms of a direct job per SUM workgroup
+#ifndef PS_RED_SUM_TERMS
+#define PS_RED_SUM_TERMS 512
+#endif
+constexpr u32 RED_SUM_TERMS = PS_RED_SUM_TERMS;   // terms of a direct job per SUM workgroup
 
 struct ReducePlan {
     u32 segs;   // segments (of RED_SEG buckets) per bucket set
