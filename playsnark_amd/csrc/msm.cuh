@@ -1008,7 +1008,10 @@ __global__ void __launch_bounds__(256) k_fixup_heavy(const Xyzz<typename FieldTr
 //   host the weights: sum = A + sum_q 2^(q+3) Q_q + sum_k 2^(k+6) T_k, a Horner chain of c-1 doublings per bucket set
 //        that takes the CPU a few tens of microseconds (msm_fold_host) and was 19 dependent doublings, 0.3 ms, on a GPU
 //        lane.
-constexpr int RED_SEG_LOG = 3;
+#ifndef PS_RED_SEG_LOG
+#define PS_RED_SEG_LOG 3
+#endif
+constexpr int RED_SEG_LOG = PS_RED_SEG_LOG;
 constexpr int RED_SEG = 1 << RED_SEG_LOG;
 constexpr int RED_DIRECT_JOBS = 4;   // A, Q0, Q1, Q2
 constexpr u32 RED_SUM_LANES = 64;    // logical threads of a SUM / FIN workgroup
