@@ -5,7 +5,7 @@ import bench
 from playsnark_amd import api
 ctx = api.Context(0)
 if os.environ.get("NOTAB"): ctx.set_tables(False)
-n = 1 << 20
+n = 1 << int(os.environ.get("LOG2N", "20"))
 if os.environ.get("CIRCUIT") == "bits":  # n booleanity gates b*b = b over [const, b_1..b_n], a witness of random bits
     import numpy as np
     ptr = np.arange(n + 1, dtype=np.uint32); col = np.arange(1, n + 1, dtype=np.uint32); val = np.ones(n, dtype=np.int64)
