@@ -845,7 +845,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const ReducePlan rp = reduce_plan(pl.NB);
     const u32 nseg_total = rp.segs * (u32)pl.sets;
     const u32 per_role = rp.m * (u32)pl.sets, nres = rp.njobs * (u32)pl.sets;
-    const bool tab = pl.sets == 1;
+    const bool tab = pl.table;
     const u32 pstride = tab ? (u32)table_row_bytes(pts->group) : (u32)sizeof(Affine<F>);
     const char* src = tab ? (const char*)pts->st->table + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
     const u32 idx_mask = tab ? (1u << ENTRY_W_SHIFT) - 1u : 0x7fffffffu;
@@ -933,6 +933,15 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
     for (size_t i = 0; i < k && tab; i++)
         tab = table_usable(c, pts[i], n, max_bits) && pts[i]->st->table_c == pts[0]->st->table_c;
     MsmPlan pl = tab ? msm_plan_table(n, max_bits, pts[0]->st->table_c) : msm_plan(n, max_bits, c->forced_c);
+    if (tab) {
+        // Short scalars (an int64 witness over a table built for 20-bit windows: 4 windows, but 2^19 buckets to reduce) are
+        // cheaper on the plain plan with its small windows -- same cost model as msm_plan: 10 field products per bucket
+        // addition, 42 per bucket of the reduction (measured at 2^20 points, 40-bit values: 1.28 ms over the table, 1.04 plain)
+        const MsmPlan plain = msm_plan(n, max_bits, 0);
+        const double cost_tab = (double)n * pl.W * 10.0 + (double)pl.G * 42.0;
+        const double cost_plain = (double)n * plain.W * 10.0 + (double)plain.G * 42.0;
+        if (cost_plain < 0.9 * cost_tab) pl = plain;
+    }
     if (c->forced_slice) pl.M = c->forced_slice;
     if ((u64)pl.W * (u64)n >= (1ull << 32))
         return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +

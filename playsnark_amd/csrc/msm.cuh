@@ -35,6 +35,7 @@ struct MsmPlan {
     int M;       // sorted entries per accumulation thread
     int SEG;     // buckets per reduction thread
     int sets;    // bucket sets: W, or 1 when the points come with their window table 2^(c w) P (all windows share one set)
+    bool table;  // the point pass reads the window table (a plain plan with a single window also has sets == 1)
 };
 // Entries of the sorted list: point index | window << ENTRY_W_SHIFT | sign << 31.  The window field is used only
 // with a window table (then the index must fit ENTRY_W_SHIFT bits); without one the index may use all 31 bits.
@@ -77,6 +78,7 @@ static inline MsmPlan msm_plan_table(size_t n, int max_bits, int c) {
     pl.W = max_bits / c + 1;
     pl.NB = 1u << (c - 1);
     pl.sets = 1;
+    pl.table = true;
     pl.G = pl.NB;
     pl.M = 32;
     const u64 total = (u64)n * pl.W;

@@ -645,7 +645,9 @@ def test_window_table_full_size_bit_exact_vs_oracle(ps_api, ctx, co, pr):
     pts.precompute(20)
     w = _witness_i64(n, 9090)
     got = ps_api.Poly.from_values(ctx, w.tolist()).BlindEval(pts)
-    assert ctx.last_msm_info()["windows"] == 4 and ctx.last_msm_info()["window_bits"] == 20
+    # an int64 witness over a 20-bit table would take 4 windows but 2^19 buckets to reduce: the cost model prefers the
+    # plain plan's small windows for short scalars (1.28 -> 1.04 ms per sum), the table stays for full-width ones
+    assert ctx.last_msm_info()["windows"] == 5 and ctx.last_msm_info()["window_bits"] == 13
     assert got == co.G1.to_b(co.G1.msm_pippenger(_i64_to_be32(w, pr.R).tobytes(), raw, n, threads))
     m = 1 << 16
     small = ps_api.Points.upload(ctx, ps_api.G1, raw[: 96 * m]).precompute(18)
