@@ -68,8 +68,10 @@ int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts,
  * 16 bucket additions per 255-bit scalar and a sixteenth of the buckets to reduce.  Results are the same group
  * elements, bit for bit.  Costs (255 / c + 1) rows of 128 B (G1) / 256 B (G2) per point in device memory (1.7 GB for
  * 2^20 G1 points at c = 20);
- * at most 2^26 - 1 points.  Sums fall back to the plain path when a table is absent, when ps_msm_set_window
- * forces a window size, or when the arrays of a ps_msm_multi call do not all carry tables of one window size. */
+ * at most 2^26 - 1 points.  Sums take the plain path when a table is absent, when ps_msm_set_window
+ * forces a window size, when the arrays of a ps_msm_multi call do not all carry tables of one window size, or when the
+ * cost model prefers it (short scalars: an int64 witness).  window_bits = -1 releases the table (after waiting for the
+ * device: sums may still read it). */
 int ps_points_precompute(ps_ctx* ctx, ps_points* p, int window_bits);
 int ps_points_table_window(const ps_points* p); /* window bits of the table, 0 = none */
 /* ps_groth16_prove / ps_phgr13_prove build the tables of their CRS arrays themselves on first use (keys of at least

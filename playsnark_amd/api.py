@@ -193,6 +193,11 @@ class Points:
         _check(lib.ps_points_precompute(self.ctx._h, self._h, window_bits))
         return self
 
+    def drop_table(self) -> "Points":
+        """Release the window table (ps_points_precompute with window_bits = -1); sums go back to the plain plan."""
+        _check(lib.ps_points_precompute(self.ctx._h, self._h, -1))
+        return self
+
     @property
     def table_window(self) -> int:
         return lib.ps_points_table_window(self._h)

@@ -572,7 +572,17 @@ static int build_table(ps_ctx* c, Storage* st, int group, int wbits, int W) {
 }
 extern "C" int ps_points_precompute(ps_ctx* c, ps_points* p, int window_bits) {
     if (!c || !p) return fail(PS_ERR_ARG, "ps_points_precompute: NULL argument");
-    if (window_bits != 0 && (window_bits < 8 || window_bits > 22)) return fail(PS_ERR_ARG, "ps_points_precompute: window bits must be 0 (automatic) or 8..22");
+    if (window_bits == -1) {  // release
+        Storage* st0 = p->st;
+        if (!st0->table) return PS_OK;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(st0->table);
+        st0->table = nullptr;
+        st0->table_c = st0->table_W = 0;
+        return PS_OK;
+    }
+    if (window_bits != 0 && (window_bits < 8 || window_bits > 22)) return fail(PS_ERR_ARG, "ps_points_precompute: window bits must be 0 (automatic), -1 (release) or 8..22");
     Storage* st = p->st;
     const size_t n = st->count;
     if (n == 0) return PS_OK;

@@ -640,6 +640,8 @@ def test_window_table_full_size_bit_exact_vs_oracle(ps_api, ctx, co, pr):
     info = ctx.last_msm_info()
     assert (info["window_bits"], info["windows"], info["buckets"]) == (c, 255 // c + 1, 1 << (c - 1)) and info["entries"] < (255 // c + 1) * n
     assert got == want
+    assert pts.drop_table().table_window == 0  # released: the plain plan again, the same bytes
+    assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want and ctx.last_msm_info()["window_bits"] == 16
     pts.precompute(19)  # a window size whose top window is nearly empty: a million entries on 116 buckets
     assert ps_api.Poly.upload(ctx, sc).BlindEval(pts) == want and ctx.last_msm_info()["window_bits"] == 19
     pts.precompute(20)
