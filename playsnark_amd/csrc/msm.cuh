@@ -68,6 +68,7 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     best.M = 32;
     const u64 total = (u64)n * best.W;
     while (best.M < 1024 && total / (2 * (u64)best.M) >= (1u << 19)) best.M *= 2;
+    while (best.M < 1024 && (u64)best.M * 5 * best.G < total) best.M *= 2;  // ... and an average bucket spans <= 5 slices (below)
     best.SEG = 8;
     return best;
 }
@@ -83,6 +84,11 @@ static inline MsmPlan msm_plan_table(size_t n, int max_bits, int c) {
     pl.M = 32;
     const u64 total = (u64)n * pl.W;
     while (pl.M < 1024 && total / (2 * (u64)pl.M) >= (1u << 19)) pl.M *= 2;
+    // An average bucket must not span more than ~5 slices: from 8 on a bucket takes the heavy path, which is built for a
+    // few enormous buckets (a workgroup per job), not for ALL of them -- 2^19 points over a 16-bit table (256 entries per
+    // bucket, M = 32) took 9.9 ms per sum instead of 1.6.  No longer than needed: a slice is a serial chain, and 2^18
+    // points at M = 64 leave one wave per SIMD (Groth16 at 2^18: 7.0 -> 7.7 ms).
+    while (pl.M < 1024 && (u64)pl.M * 5 * pl.G < total) pl.M *= 2;
     pl.SEG = 8;
     return pl;
 }

@@ -681,3 +681,30 @@ def test_wire_values_of_a_boolean_circuit_over_a_window_table(ps_api, ctx, co, p
     total = sum(int.from_bytes(seeds[i].tobytes(), "big") for i in np.nonzero(bits)[0]) % pr.R
     assert got == co.G1.to_b(co.G1.mul(total))
     assert ms < 25, f"{ms:.1f} ms for a 2^20-point sum of 0/1 scalars"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n", [17, 19])
+def test_dense_buckets_do_not_take_the_heavy_path(ps_api, ctx, co, pr, log2n):
+    """Lengths whose automatic table window leaves hundreds of entries per bucket (2^19 points over a 16-bit table: 256):
+    the slice length follows the bucket size, so an average bucket spans a few slices and not the eight that route it to
+    the heavy-bucket kernels -- 2^19 points once took 9.9 ms per sum, more than 2^21.  Additivity of the sum in the
+    scalars for the bytes, a generous bound for the time."""
+    import time
+
+    n = 1 << log2n
+    pts = ps_api.Points.from_scalars(ctx, ps_api.G1, ps_api.Poly.upload(ctx, _uniform_be32(n, 3131).tobytes())).precompute()
+    a, b = _uniform_be32(n, 3132), _uniform_be32(n, 3133)
+    pa, pb = ps_api.Poly.upload(ctx, a.tobytes()), ps_api.Poly.upload(ctx, b.tobytes())
+    ra = pa.BlindEval(pts)
+    info = ctx.last_msm_info()
+    assert info["entries"] <= 5 * info["slice"] * info["buckets"], info  # an average bucket spans at most five slices
+    ctx.sync()
+    t0 = time.perf_counter()
+    rb = pb.BlindEval(pts)
+    ms = (time.perf_counter() - t0) * 1e3
+    ia = [int.from_bytes(a[i].tobytes(), "big") for i in range(n)]
+    ib = [int.from_bytes(b[i].tobytes(), "big") for i in range(n)]
+    ab = ps_api.Poly.upload(ctx, [(x + y) % pr.R for x, y in zip(ia, ib)])
+    assert ps_api.points_sum(ps_api.G1, ra + rb) == ab.BlindEval(pts)
+    assert ms < 6, f"{ms:.1f} ms for a 2^{log2n}-point sum"
