@@ -69,6 +69,7 @@ static inline MsmPlan msm_plan(size_t n, int max_bits, int forced_c) {
     const u64 total = (u64)n * best.W;
     while (best.M < 1024 && total / (2 * (u64)best.M) >= (1u << 19)) best.M *= 2;
     while (best.M < 1024 && (u64)best.M * 5 * best.G < total) best.M *= 2;  // ... and an average bucket spans <= 5 slices (below)
+    while (best.M > 8 && total / (u64)best.M < (1u << 17) && (u64)(best.M / 2) * 5 * best.G >= total) best.M /= 2;  // short sums (below)
     best.SEG = 8;
     return best;
 }
@@ -89,6 +90,9 @@ static inline MsmPlan msm_plan_table(size_t n, int max_bits, int c) {
     // bucket, M = 32) took 9.9 ms per sum instead of 1.6.  No longer than needed: a slice is a serial chain, and 2^18
     // points at M = 64 leave one wave per SIMD (Groth16 at 2^18: 7.0 -> 7.7 ms).
     while (pl.M < 1024 && (u64)pl.M * 5 * pl.G < total) pl.M *= 2;
+    // Short sums are latency-bound and a slice is a serial chain of M additions (10 us each): while there are fewer
+    // than 2^17 threads (two waves per SIMD), halve it -- down to 8, and never past the five-slice rule above.
+    while (pl.M > 8 && total / (u64)pl.M < (1u << 17) && (u64)(pl.M / 2) * 5 * pl.G >= total) pl.M /= 2;
     pl.SEG = 8;
     return pl;
 }
