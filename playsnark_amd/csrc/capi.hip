@@ -937,20 +937,25 @@ static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int ma
     // a forced window size means "the plain path with this c" (A/B runs); entries keep 26 bits for the index
     return st->table && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
 }
+#ifndef PS_TABLE_COST_MARGIN
+#define PS_TABLE_COST_MARGIN 0.9  // the plain plan must be this much cheaper in the model to replace a table that exists
+#endif
 static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t k, size_t n, int max_bits, MsmPlan* out) {
     // The window-table plan needs every array of the call to carry a table for the same window size
     bool tab = k > 0;
     for (size_t i = 0; i < k && tab; i++)
         tab = table_usable(c, pts[i], n, max_bits) && pts[i]->st->table_c == pts[0]->st->table_c;
     MsmPlan pl = tab ? msm_plan_table(n, max_bits, pts[0]->st->table_c) : msm_plan(n, max_bits, c->forced_c);
-    if (tab) {
+    if (tab && k == 1) {
         // Short scalars (an int64 witness over a table built for 20-bit windows: 4 windows, but 2^19 buckets to reduce) are
         // cheaper on the plain plan with its small windows -- same cost model as msm_plan: 10 field products per bucket
-        // addition, 42 per bucket of the reduction (measured at 2^20 points, 40-bit values: 1.28 ms over the table, 1.04 plain)
+        // addition, 42 per bucket of the reduction (measured at 2^20 points, 40-bit values: 1.28 ms over the table, 1.04 plain).
+        // One array only: for the seven sums of PHGR13 over ONE sort the tables stay (2^20 booleanity gates: 10.3 ms against
+        // 12.0 with the plain plan -- five bucket sets per array, a fifth more digits to sort).
         const MsmPlan plain = msm_plan(n, max_bits, 0);
         const double cost_tab = (double)n * pl.W * 10.0 + (double)pl.G * 42.0;
         const double cost_plain = (double)n * plain.W * 10.0 + (double)plain.G * 42.0;
-        if (cost_plain < 0.9 * cost_tab) pl = plain;
+        if (cost_plain < PS_TABLE_COST_MARGIN * cost_tab) pl = plain;
     }
     if (c->forced_slice) pl.M = c->forced_slice;
     if ((u64)pl.W * (u64)n >= (1ull << 32))
