@@ -906,18 +906,23 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         Xyzz<F>* runs = accs + nseg_total;
         Xyzz<F>* lvl = runs + nseg_total;
         Xyzz<F>* pieces = lvl + 5 * (size_t)per_role;
-        hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
-                           nseg_total, accs, runs);
-        hipLaunchKernelGGL(k_reduce_pyr<KF>, dim3(nblocks(5 * (size_t)per_role * LN)), dim3(256), 0, st, (const Xyzz<F>*)accs,
-                           (const Xyzz<F>*)runs, rp.segs, rp.m, (u32)pl.sets, lvl);
-        hipLaunchKernelGGL(k_reduce_sum<KF>, dim3(nres * rp.nblk), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
-                           (const Xyzz<F>*)lvl, rp.m, (u32)pl.sets, rp.njobs, rp.nblk, rp.nblk > 1 ? pieces : (Xyzz<F>*)wc->wins.p);
-        if (rp.nblk > 1)
-            hipLaunchKernelGGL(k_reduce_fin<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
-                               (const Xyzz<F>*)pieces, rp.nblk, (Xyzz<F>*)wc->wins.p);
+        if (rp.small) {
+            hipLaunchKernelGGL(k_reduce_small<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                               (const Xyzz<F>*)wc->buckets.p, pl.NB, rp.njobs, (Xyzz<F>*)wc->wins.p);
+        } else {
+            hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
+                               nseg_total, accs, runs);
+            hipLaunchKernelGGL(k_reduce_pyr<KF>, dim3(nblocks(5 * (size_t)per_role * LN)), dim3(256), 0, st, (const Xyzz<F>*)accs,
+                               (const Xyzz<F>*)runs, rp.segs, rp.m, (u32)pl.sets, lvl);
+            hipLaunchKernelGGL(k_reduce_sum<KF>, dim3(nres * rp.nblk), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                               (const Xyzz<F>*)lvl, rp.m, (u32)pl.sets, rp.njobs, rp.nblk, rp.nblk > 1 ? pieces : (Xyzz<F>*)wc->wins.p);
+            if (rp.nblk > 1)
+                hipLaunchKernelGGL(k_reduce_fin<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
+                                   (const Xyzz<F>*)pieces, rp.nblk, (Xyzz<F>*)wc->wins.p);
+        }
         if (pl.sets > 1)  // per-set weights on the device; the set sums follow the partial results in `wins`
             hipLaunchKernelGGL(k_reduce_weights<KF>, dim3((unsigned)pl.sets), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
-                               (const Xyzz<F>*)wc->wins.p, rp.njobs, (Xyzz<F>*)wc->wins.p + nres);
+                               (const Xyzz<F>*)wc->wins.p, rp.njobs, rp.small ? 1 : 0, (Xyzz<F>*)wc->wins.p + nres);
     }
     PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
@@ -983,12 +988,19 @@ static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) 
     if (pl.sets == 1) {
         // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
         const ReducePlan rp = reduce_plan(pl.NB);
-        for (int j = (int)rp.njobs - 1; j >= 1; j--) {
-            acc = xyzz_dbl<H>(acc);
-            xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
+        if (rp.small) {  // V_0 .. V_{c-1} of k_reduce_small: sum = sum_k 2^k V_k
+            for (int j = (int)rp.njobs - 1; j >= 0; j--) {
+                acc = xyzz_dbl<H>(acc);
+                xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
+            }
+        } else {
+            for (int j = (int)rp.njobs - 1; j >= 1; j--) {
+                acc = xyzz_dbl<H>(acc);
+                xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
+            }
+            for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<H>(acc);
+            xyzz_add<H>(acc, xyzz_to_host<F>(res[0]));
         }
-        for (int i = 0; i < RED_SEG_LOG; i++) acc = xyzz_dbl<H>(acc);
-        xyzz_add<H>(acc, xyzz_to_host<F>(res[0]));
     } else {
         for (int w = pl.sets - 1; w >= 0; w--) {  // Horner over the window sums (k_reduce_weights made them)
             for (int i = 0; i < pl.c; i++) acc = xyzz_dbl<H>(acc);

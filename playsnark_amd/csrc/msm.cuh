@@ -1038,9 +1038,20 @@ struct ReducePlan {
     int kb;     // log2(m): bit jobs
     u32 njobs;  // RED_DIRECT_JOBS + kb results per bucket set, in the order A, Q0, Q1, Q2, T_0 .. T_{kb-1}
     u32 nblk;   // SUM workgroups per job
+    bool small; // NB <= RED_SMALL_NB: one kernel, njobs = c results V_0 .. V_{c-1} (k_reduce_small)
 };
+constexpr u32 RED_SMALL_NB = 1024;
 static inline ReducePlan reduce_plan(u32 NB) {
     ReducePlan r;
+    r.small = NB <= RED_SMALL_NB;
+    if (r.small) {
+        r.segs = r.m = 0;
+        r.kb = 0;
+        r.njobs = 1;
+        while ((1u << (r.njobs - 1)) < NB) r.njobs++;  // NB = 2^(c-1): c jobs
+        r.nblk = 1;
+        return r;
+    }
     r.segs = NB >> RED_SEG_LOG;
     r.m = r.segs >= 8 ? r.segs / 8 : 1;
     r.kb = 0;
@@ -1142,19 +1153,46 @@ __global__ void __launch_bounds__(128) k_reduce_fin(const Xyzz<typename FieldTra
     if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
 }
 
+// Small bucket sets (NB <= 1024: short sums, where the chain of kernels above is pure latency -- 28 dependent additions for
+// 512 buckets): sum_b (b+1) B[b] straight from the bits of v = b + 1, V_k = the sum of the buckets whose v has bit k, one
+// single-wave workgroup per (set, k): NB / 128 additions in a row, then the LDS tree.  sum = sum_k 2^k V_k.
+template <class KF>
+__global__ void __launch_bounds__(128) k_reduce_small(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets, u32 NB, u32 c,
+                                                      Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    typedef typename FieldTraits<KF>::Store S;
+    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
+    const u32 set = blockIdx.x / c, k = blockIdx.x % c, lt = logical_local<KF>();
+    const Xyzz<S>* B = buckets + (size_t)set * NB;
+    Xyzz<KF> acc = xyzz_identity<KF>();
+    if (k + 1 < c) {  // v in [1, NB) with bit k set: insert a 1 at position k of t
+        const u32 low = (1u << k) - 1u;
+        for (u32 t = lt; t < (NB >> 1); t += RED_SUM_LANES) {
+            const u32 v = ((t & ~low) << 1) | (1u << k) | (t & low);
+            Xyzz<KF> b = ld_xyzz<KF>(&B[v - 1]);
+            xyzz_add_inl<KF>(acc, b);
+        }
+    } else if (lt == 0) {  // v = NB, the only value with bit c - 1
+        acc = ld_xyzz<KF>(&B[NB - 1]);
+    }
+    block_tree_sum<KF>(sm, acc);
+    if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
+}
+
 // Several bucket sets (the plain plan: one per window): the weights 2^(j+2) of a set's partial results are applied here,
 // one workgroup per set -- every lane doubles its own result, then an LDS tree -- because W Horner chains of c - 1
 // doublings each would cost the host's scalar code more (0.4 ms at W = 16) than the 0.15 ms this takes.  With ONE set
 // (window tables) the chain is 19 doublings, 50 us on the host, and the kernel is skipped.
 template <class KF>
-__global__ void __launch_bounds__(128) k_reduce_weights(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ res, u32 njobs,
+__global__ void __launch_bounds__(128) k_reduce_weights(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ res, u32 njobs, int small,
                                                         Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
     const u32 lt = logical_local<KF>();
     Xyzz<KF> v = lt < njobs ? ld_xyzz<KF>(&res[(size_t)blockIdx.x * njobs + lt]) : xyzz_identity<KF>();
-    const int shift = (lt == 0 || lt >= njobs) ? 0 : (int)lt - 1 + RED_SEG_LOG;  // A: 1; job j >= 1: 8 * 2^(j-1)
+    // results of k_reduce_small: V_j weighs 2^j; of the pyramid: A weighs 1, job j >= 1 weighs 8 * 2^(j-1)
+    const int shift = lt >= njobs ? 0 : small ? (int)lt : (lt == 0 ? 0 : (int)lt - 1 + RED_SEG_LOG);
     for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
     block_tree_sum<KF>(sm, v);
     if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
