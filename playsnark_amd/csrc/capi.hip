@@ -970,6 +970,9 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
     return PS_OK;
 }
 
+#ifndef PS_CHAIN_MIN_ENTRIES
+#define PS_CHAIN_MIN_ENTRIES (1ull << 21)  // sums with fewer digits than this are not chained behind the previous accumulation
+#endif
 static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl, hipEvent_t wait_acc,
                           hipEvent_t acc_done) {
     int rc = msm_sort(wc, sc, pl, wc->timing);
@@ -1048,7 +1051,8 @@ static int msm_multi_points(ps_ctx* c, ps_ctx* const* ring, const ps_points* con
         if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
         if (!c->ev_acc[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming));
         ps_ctx* wc = ring[i % PS_MULTI_RING];
-        hipEvent_t wait = i ? c->ev_acc[i - 1] : first_wait;
+        const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;  // short sums run side by side (msm_launch_impl)
+        hipEvent_t wait = !chained ? nullptr : i ? c->ev_acc[i - 1] : first_wait;
         int rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i])
                                         : msm_points_t<Fp2>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i]);
         if (rc) {
@@ -1168,7 +1172,11 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         if (rc0) return rc0;
         if (wc != c) HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
         // chain the accumulations: this one starts when the previously launched one is done
-        hipEvent_t wait = (c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
+        // ... unless the sum is short: accumulations of a few hundred thousand entries do not fill the chip, and chained
+        // they are three launch latencies in a row (A/B on one box: Groth16 on 2^10 constraints 1.62 -> 1.54 ms, PHGR13 on 2^14 4.25 -> 3.9 ms;
+        // below that the host's ~25 launches per sum are the bound)
+        const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;
+        hipEvent_t wait = (chained && c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
         int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr);
         if (rc) return rc;
         c->last_chain = wc;
