@@ -794,7 +794,8 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         u32* coarse_cur = coarse_off + SORT_MAX_COARSE + 1;
         u32* tile_base = coarse_cur + SORT_MAX_COARSE + 1;
         HIP_TRY(hipMemsetAsync(coarse_cnt, 0, 4 * SORT_MAX_COARSE, st));
-        HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));  // per-bucket counters of the big bins (k_sort_big_*)
+        const bool may_have_big_bins = total > SORT_BIG;  // a bin of more than SORT_BIG entries needs that many digits
+        if (may_have_big_bins) HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));  // per-bucket counters of the big bins (k_sort_big_*)
         hipLaunchKernelGGL(k_sort_count, dgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
                            single, ncoarse, fb, (u32*)c->ranks.p, coarse_cnt);
         PS_STAGE_MARK();  // 1: after digits + coarse histogram
@@ -805,8 +806,10 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         PS_STAGE_MARK();  // 2: after scan + partition
         hipLaunchKernelGGL(k_sort_fine, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)c->vals.p,
                            (const u32*)coarse_off, (u32)G, fb, (u32*)c->offs.p, (u32*)c->sorted.p);
-        // bins with more than SORT_BIG entries, tile by tile (no tiles: the three kernels return at once)
+        // bins with more than SORT_BIG entries, tile by tile (no tiles: the three kernels return at once; short sums, which
+        // are bound by the number of launches, skip them)
         const unsigned big_grid = (unsigned)std::min<u64>(2048, total / SORT_TILE + 1);
+        if (may_have_big_bins) {
         hipLaunchKernelGGL(k_sort_big_count, dim3(big_grid), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p, (const u32*)coarse_off,
                            (const u32*)tile_base, ncoarse, fb, (u32*)c->counts.p);
         hipLaunchKernelGGL(k_sort_big_scan, dim3(ncoarse), dim3(SORT_FINE), 0, st, (const u32*)coarse_off, (u32)G, fb, (u32*)c->counts.p,
@@ -814,6 +817,7 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         hipLaunchKernelGGL(k_sort_big_scatter, dim3(big_grid), dim3(SORT_FINE), 0, st, (const unsigned short*)c->keys.p,
                            (const u32*)c->vals.p, (const u32*)coarse_off, (const u32*)tile_base, ncoarse, fb, (u32*)c->counts.p,
                            (u32*)c->sorted.p);
+        }
     } else {
         HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));
         {
