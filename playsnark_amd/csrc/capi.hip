@@ -880,7 +880,6 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
     if (storage_wait_ready(pts->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced points
     HIP_TRY(hipMemsetAsync(wc->heavy.p, 0, 4, st));
-    HIP_TRY(hipMemsetAsync(wc->buckets.p, 0, sizeof(Xyzz<F>) * G, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
     PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
     constexpr bool PF = LN == 1 || PS_G2_ACC_WAVES == 1;  // next point prefetched (the lane-pair G2 kernel at two waves per SIMD has no registers to spare)

@@ -890,7 +890,11 @@ __global__ void __launch_bounds__(256, 1) k_fixup(const u32* __restrict__ offs, 
     u32 g = logical_tid<KF>();
     if (g >= G) return;
     u32 lo = offs[g], hi = offs[g + 1];
-    if (lo == hi) return;  // empty bucket: stays the identity from the memset
+    if (lo == hi) {  // empty bucket: the identity (no memset of the bucket array: every bucket is written by exactly one of the
+                     // accumulation's flush, this kernel and k_fixup_heavy)
+        st_xyzz<KF>(&buckets[g], xyzz_identity<KF>());
+        return;
+    }
     u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
     if (t0 == t1) return;  // lay inside one slice: already final
     if (t1 - t0 >= HEAVY_SPAN) {  // long chain: one workgroup per bucket instead of one thread
