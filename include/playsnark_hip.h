@@ -159,6 +159,10 @@ typedef struct {
 int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
 int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic, else 4..20 */);
 int ps_msm_set_slice(ps_ctx* ctx, int entries /* sorted entries per accumulation thread; 0 = automatic */);
+/* The tail of a sum (fix-up of cut buckets, bucket reduction): 0 = automatic (short sums -- fewer than 2^21 digits --
+ * take shallow trees of lane-cooperative point additions, long ones the work-efficient chains), 1 = chains, 2 = trees.
+ * Same group element, same bytes, either way (A/B runs and tests). */
+int ps_msm_set_tail(ps_ctx* ctx, int mode);
 /* Per-stage device time of the sum finished last, measured with HIP events on the streams its kernels
  * run on.  Stages: 0 digits (+counter memset), 1 scan, 2 scatter, 3 queue (bucket memset, and with
  * several sums in flight the wait for the previous sum's accumulation), 4 accumulate (the dominant

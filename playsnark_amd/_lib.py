@@ -26,7 +26,7 @@ SYMBOLS = [
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
-    "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
+    "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_msm_set_tail", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_qap_interpolate", "ps_poly_mul",
     "ps_points_lincomb", "ps_msm_multi_device", "ps_groth16_prove_multi",
     "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_groth16_prove_shard", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
@@ -152,6 +152,7 @@ def _load():
     lib.ps_msm_set_window.argtypes = [vp, i]
     lib.ps_ctx_set_timing.argtypes = [vp, i]
     lib.ps_msm_set_slice.argtypes = [vp, i]
+    lib.ps_msm_set_tail.argtypes = [vp, i]
     lib.ps_msm_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ps_qap_create.argtypes = [vp, sz, sz, sz, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), pp]
     lib.ps_qap_free.argtypes = [vp]

@@ -80,6 +80,10 @@ class Context:
     def set_slice(self, entries: int):
         _check(lib.ps_msm_set_slice(self._h, entries))
 
+    def set_tail(self, mode: int):
+        """0 automatic, 1 chains (the long sums' tail), 2 trees of lane-cooperative additions (the short sums' tail)."""
+        _check(lib.ps_msm_set_tail(self._h, mode))
+
     STAGES = ("digits", "scan", "scatter", "queue", "accumulate", "fixup", "reduce")
 
     def set_timing(self, enable: bool):

@@ -67,7 +67,7 @@ struct DevBuf {
     }
 };
 
-constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>);  // what the host folds: window sums (W <= 64) or one set's partial results (<= 21)
+constexpr size_t PS_PINNED_SLOT = 64 * sizeof(Xyzz<Fp2>) + 16;  // what the host folds: window sums (W <= 64) or one set's partial results (<= 21), then the entry count of a short sum
 
 struct ps_ctx {
     int device = 0;
@@ -106,6 +106,7 @@ struct ps_ctx {
     ps_msm_info last_info{};
     int forced_c = 0;
     int forced_slice = 0;
+    int forced_tail = 0;             // ps_msm_set_tail: 0 automatic, 1 chains, 2 trees of lane-cooperative additions
     QuotientCache* qcache = nullptr;
     // Groth16 fused driver: secondary context (own stream + workspace) for the concurrent G2 MSM,
     // and the concatenated CRS arrays of the last proving key
@@ -838,8 +839,8 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     }
     PS_STAGE_MARK();  // 3: after scatter
     HIP_TRY(hipGetLastError());
-    // entry count for introspection (read back with the window sums)
-    HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + c->h_pinned_cap - 8, (u32*)c->offs.p + G, 4, hipMemcpyDeviceToHost, st));
+    // entry count for introspection (read back with the window sums; a short sum's last kernel appends it to its results)
+    if (!pl.qtail) HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + c->h_pinned_cap - 8, (u32*)c->offs.p + G, 4, hipMemcpyDeviceToHost, st));
     return PS_OK;
 }
 
@@ -850,13 +851,20 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
 // wait_acc: event the accumulation waits for; acc_done: recorded right after it.
 template <class F>
 static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, const MsmPlan& pl, bool timed, int slot,
-                        hipEvent_t wait_acc, hipEvent_t acc_done) {
+                        hipEvent_t wait_acc, hipEvent_t acc_done, bool inline_tail = false) {
     typedef typename KernelField<F>::type KF;      // Fp -> Fp, Fp2 -> lane-split Fp2s
     constexpr unsigned LN = FieldTraits<KF>::LANES;  // lanes per logical thread
     const u64 total = (u64)pl.W * n;
     const u64 G = pl.G;
     const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
-    const ReducePlan rp = reduce_plan(pl.NB);
+    ReducePlan rp = reduce_plan(pl.NB);
+    if (pl.qtail) {  // row sums and column sums in `segs`, c results per set: [S, W_0 .. W_{c-2}] (qtail.cuh)
+        rp.small = false;
+        rp.njobs = (u32)pl.c;
+        rp.nblk = 1;
+        rp.m = 0;
+        rp.segs = ((1u << (pl.c - 1 - pl.rc_s)) + (1u << pl.rc_s) + 1) / 2;  // two arrays of `segs` points hold R and C
+    }
     const u32 nseg_total = rp.segs * (u32)pl.sets;
     const u32 per_role = rp.m * (u32)pl.sets, nres = rp.njobs * (u32)pl.sets;
     const bool tab = pl.table;
@@ -868,29 +876,34 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
     if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + 5 * (size_t)per_role + (size_t)nres * rp.nblk)))) return rc;
-    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * ((size_t)nres + (size_t)pl.sets)))) return rc;
+    if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * ((size_t)nres + (size_t)pl.sets) + 16))) return rc;
     const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
     const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
-    if (sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
+    if (sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) + 16 > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
     int evi = 4;  // ev[3] = after the scatter (msm_sort); ev[4] = the accumulation may start
     if (wc->tail_used) HIP_TRY(hipStreamWaitEvent(st, wc->ev_tail_done, 0));  // buffers of the previous sum
     if (storage_wait_ready(pts->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced points
-    HIP_TRY(hipMemsetAsync(wc->heavy.p, 0, 4, st));
     if (wait_acc) HIP_TRY(hipStreamWaitEvent(st, wait_acc, 0));
     PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
     constexpr bool PF = LN == 1 || PS_G2_ACC_WAVES == 1;  // next point prefetched (the lane-pair G2 kernel at two waves per SIMD has no registers to spare)
     hipLaunchKernelGGL((k_accumulate<KF, PF>), dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, src,
                        (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, idx_mask, w_stride, pstride,
-                       (Xyzz<F>*)wc->buckets.p, (Xyzz<F>*)wc->parts.p);
+                       (Xyzz<F>*)wc->buckets.p, (Xyzz<F>*)wc->parts.p, (u32*)wc->heavy.p);
     if (acc_done) HIP_TRY(hipEventRecord(acc_done, st));
     PS_STAGE_MARK();  // 5: after accumulate
     HIP_TRY(hipEventRecord(wc->ev_acc_local, st));
-    st = wc->tail;  // ---- the rest runs on the high-priority tail stream ----
-    HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
+    if (!inline_tail) {  // a lone short sum keeps one stream: the hop to the tail stream costs it ~10 us and buys nothing
+        st = wc->tail;   // ---- the rest runs on the high-priority tail stream ----
+        HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
+    }
+    if (pl.qtail && pl.lpb >= 1)
+        hipLaunchKernelGGL(k_qfixup<KF>, dim3(nblocks(G * (u64)pl.lpb * QTraits<KF>::GL)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
+                           (u32)pl.lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
+    else
     hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     {
@@ -909,7 +922,27 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         Xyzz<F>* runs = accs + nseg_total;
         Xyzz<F>* lvl = runs + nseg_total;
         Xyzz<F>* pieces = lvl + 5 * (size_t)per_role;
-        if (rp.small) {
+        if (pl.qtail) {
+            // row / column sums, then the bit sums of both (qtail.cuh); small sets: the bit sums straight from the buckets
+            constexpr u32 QGL = QTraits<KF>::GL, QNP = 512 / QGL;
+            const int cb = pl.c - 1, s = pl.rc_s;
+            const u32 rows = 1u << (cb - s), cols = 1u << s;
+            Xyzz<F>* R = accs;
+            Xyzz<F>* C = accs + (size_t)pl.sets * rows;
+            if (s > 0) {
+                // quads per row / column job: all jobs resident at once (a quad kernel holds ~250 VGPRs: 8 waves per CU,
+                // 2048 on the chip -- a second round of blocks would double the kernel's time), at most one term per quad
+                u32 np = std::min<u32>(QNP, std::max(rows, cols));
+                while (np > 64 / QGL && (u64)np * QGL * (rows + cols) * (u32)pl.sets > 2048ull * 64) np >>= 1;
+                hipLaunchKernelGGL(k_qreduce_rowcol<KF>, dim3((rows + cols) * (u32)pl.sets), dim3(np * QGL), np * QGL * sizeof(Fp), st,
+                                   (const Xyzz<F>*)wc->buckets.p, cb, s, R, C);
+            }
+            const u32 terms = std::max(rows, cols / 2);
+            const u32 np = std::min<u32>(QNP, std::max<u32>(terms, 64 / QGL));
+            hipLaunchKernelGGL(k_qreduce_bits<KF>, dim3(nres), dim3(np * QGL), np * QGL * sizeof(Fp), st,
+                               s > 0 ? (const Xyzz<F>*)R : (const Xyzz<F>*)wc->buckets.p, (const Xyzz<F>*)C, cb, s, (Xyzz<F>*)wc->wins.p,
+                               (const u32*)c->offs.p + G, (u32*)((Xyzz<F>*)wc->wins.p + (pl.sets > 1 ? nres + (size_t)pl.sets : (size_t)nres)));
+        } else if (rp.small) {
             hipLaunchKernelGGL(k_reduce_small<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
                                (const Xyzz<F>*)wc->buckets.p, pl.NB, rp.njobs, (Xyzz<F>*)wc->wins.p);
         } else {
@@ -925,13 +958,14 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         }
         if (pl.sets > 1)  // per-set weights on the device; the set sums follow the partial results in `wins`
             hipLaunchKernelGGL(k_reduce_weights<KF>, dim3((unsigned)pl.sets), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
-                               (const Xyzz<F>*)wc->wins.p, rp.njobs, rp.small ? 1 : 0, (Xyzz<F>*)wc->wins.p + nres);
+                               (const Xyzz<F>*)wc->wins.p, rp.njobs, (rp.small && !pl.qtail) ? 1 : 0, pl.qtail ? 0 : RED_SEG_LOG,
+                               (Xyzz<F>*)wc->wins.p + nres);
     }
     PS_STAGE_MARK();  // 7: after reduction
     HIP_TRY(hipGetLastError());
     // one set: its partial results (the host applies the weights); several: the set sums
     HIP_TRY(hipMemcpyAsync((char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT, (const Xyzz<F>*)wc->wins.p + (pl.sets > 1 ? nres : 0),
-                           sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres), hipMemcpyDeviceToHost, st));
+                           sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) + (pl.qtail ? 4 : 0), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(wc->ev_tail_done, st));
     wc->tail_used = true;
     return PS_OK;
@@ -945,6 +979,41 @@ static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int ma
     // a forced window size means "the plain path with this c" (A/B runs); entries keep 26 bits for the index
     return st->table && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
 }
+// Short sums (fewer than PS_QTAIL_MAX_ENTRIES digits): the chip is mostly idle behind the accumulation and the sum's time
+// is the depth of its dependency chain, so the tail runs as trees of lane-cooperative additions (qtail.cuh) and the slices
+// are as short as keeps one wave per SIMD busy.  forced: 0 automatic, 1 the chains of the long sums, 2 the trees.
+#ifndef PS_QTAIL_MAX_ENTRIES
+#define PS_QTAIL_MAX_ENTRIES (1ull << 21)
+#endif
+static void msm_plan_lpb(MsmPlan& pl, size_t n, int group) {
+    // quads per cut bucket: enough for the average span, within one 256-thread block and 2^17 lanes in all
+    const u32 gl = group == PS_G1 ? 4 : 8;
+    const u64 total = (u64)pl.W * n;
+    const u64 span = total / (pl.G * (u64)pl.M) + 1;  // slices an average bucket touches, rounded up
+    if (pl.G * (u64)gl > (1ull << 17)) { pl.lpb = 0; return; }  // too many buckets for a quad each: one thread per bucket (k_fixup)
+    u32 lpb = 1;
+    while (lpb < span && lpb * 2 * gl <= 256 && pl.G * (u64)(lpb * 2) * gl <= (1ull << 17)) lpb *= 2;  // one round of blocks (2048 waves)
+    pl.lpb = (int)lpb;
+}
+static void msm_plan_tail(MsmPlan& pl, size_t n, int group, int forced, bool busy) {
+    const u64 total = (u64)pl.W * n;
+    pl.qtail = forced ? forced == 2 : (total < PS_QTAIL_MAX_ENTRIES && pl.NB <= (1u << 16));
+    pl.lpb = 0;
+    pl.rc_s = 0;
+    if (!pl.qtail) return;
+    const u32 np = 512 / (group == PS_G1 ? 4 : 8);  // quads of a reduction block
+    const int cb = pl.c - 1;
+    pl.rc_s = (pl.NB / 2 <= 2 * np) ? 0 : (cb + 1) / 2;  // small sets: bit sums straight from the buckets
+    if (!forced || total < PS_QTAIL_MAX_ENTRIES) {
+        // one wave per SIMD when the sum is alone (the shortest chain that still fills the chip); two when other sums are in
+        // flight (2^16 points, A/B on one box: slices of 16 / 8 entries 0.504 / 0.519 ms alone, 0.348 / 0.328 in flight)
+        const u64 threads = (group == PS_G1 ? (1ull << 16) : (1ull << 15)) << (busy ? 1 : 0);
+        int M = 2;
+        while (M < 32 && total / (u64)M > threads) M *= 2;
+        pl.M = M;
+    }
+}
+
 #ifndef PS_TABLE_COST_MARGIN
 #define PS_TABLE_COST_MARGIN 0.9  // the plain plan must be this much cheaper in the model to replace a table that exists
 #endif
@@ -965,7 +1034,9 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
         const double cost_plain = (double)n * plain.W * 10.0 + (double)plain.G * 42.0;
         if (cost_plain < PS_TABLE_COST_MARGIN * cost_tab) pl = plain;
     }
+    msm_plan_tail(pl, n, k ? pts[0]->group : PS_G1, c->forced_tail, c->q_len > 0);
     if (c->forced_slice) pl.M = c->forced_slice;
+    if (pl.qtail) msm_plan_lpb(pl, n, k ? pts[0]->group : PS_G1);
     if ((u64)pl.W * (u64)n >= (1ull << 32))
         return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +
                                     " digits do not fit the 32-bit sort offsets (split the sum, e.g. ps_points_slice)");
@@ -977,11 +1048,11 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
 #define PS_CHAIN_MIN_ENTRIES (1ull << 21)  // sums with fewer digits than this are not chained behind the previous accumulation
 #endif
 static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl, hipEvent_t wait_acc,
-                          hipEvent_t acc_done) {
+                          hipEvent_t acc_done, bool inline_tail) {
     int rc = msm_sort(wc, sc, pl, wc->timing);
     if (rc) return rc;
-    rc = pts->group == PS_G1 ? msm_points_t<Fp>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done)
-                             : msm_points_t<Fp2>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done);
+    rc = pts->group == PS_G1 ? msm_points_t<Fp>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done, inline_tail)
+                             : msm_points_t<Fp2>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done, inline_tail);
     wc->ev_valid = wc->timing && !rc;
     return rc;
 }
@@ -994,7 +1065,13 @@ static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) 
     if (pl.sets == 1) {
         // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
         const ReducePlan rp = reduce_plan(pl.NB);
-        if (rp.small) {  // V_0 .. V_{c-1} of k_reduce_small: sum = sum_k 2^k V_k
+        if (pl.qtail) {  // [S, W_0 .. W_{c-2}] of k_qreduce_bits: sum = S + sum_k 2^k W_k
+            for (int j = pl.c - 1; j >= 1; j--) {
+                acc = xyzz_dbl<H>(acc);
+                xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
+            }
+            xyzz_add<H>(acc, xyzz_to_host<F>(res[0]));
+        } else if (rp.small) {  // V_0 .. V_{c-1} of k_reduce_small: sum = sum_k 2^k V_k
             for (int j = (int)rp.njobs - 1; j >= 0; j--) {
                 acc = xyzz_dbl<H>(acc);
                 xyzz_add<H>(acc, xyzz_to_host<F>(res[j]));
@@ -1014,6 +1091,13 @@ static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) 
         }
     }
     write_affine(out, acc);
+}
+
+// digits that were not zero (introspection): behind the results of slot 0 for a short sum, else in the pinned buffer's tail
+static u32 msm_entries(const ps_ctx* c, const MsmPlan& pl, int group) {
+    if (!pl.qtail) return *(const u32*)((const char*)c->h_pinned + c->h_pinned_cap - 8);
+    const size_t pt = group == PS_G1 ? sizeof(Xyzz<Fp>) : sizeof(Xyzz<Fp2>);
+    return *(const u32*)((const char*)c->h_pinned + pt * (pl.sets > 1 ? (size_t)pl.sets : (size_t)pl.c));
 }
 
 static void write_identity(int group, uint8_t* out) {  // zero.Clone(), algebra.go:353
@@ -1090,8 +1174,7 @@ static int msm_multi_finish(ps_ctx* c, ps_ctx* w0, const ps_points* const* pts, 
         if (pts[i]->group == PS_G1) msm_fold_host<Fp>(w0, pl, (int)i, out[i]);
         else msm_fold_host<Fp2>(w0, pl, (int)i, out[i]);
     }
-    u32 entries = *(u32*)((char*)w0->h_pinned + w0->h_pinned_cap - 8);
-    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(w0, pl, pts[0]->group), pl.G, pl.M};
     return PS_OK;
 }
 
@@ -1157,6 +1240,7 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         wc->timing = c->timing;
         wc->forced_c = c->forced_c;
         wc->forced_slice = c->forced_slice;
+        wc->forced_tail = c->forced_tail;
     }
     // Inputs enqueued on the context stream before the FIRST launch of a burst are visible to the worker
     // streams: the fork event is recorded while the queue is empty, ahead of that launch's own kernels
@@ -1180,7 +1264,7 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         // below that the host's ~25 launches per sum are the bound)
         const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;
         hipEvent_t wait = (chained && c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
-        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr);
+        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr, pl.qtail && c->q_len == 0);
         if (rc) return rc;
         c->last_chain = wc;
         e = {pts->group, pl, wc};
@@ -1204,11 +1288,10 @@ extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
         return PS_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(e.wc->tail));  // ordered after everything the sum put on wc->stream
+    HIP_TRY(hipEventSynchronize(e.wc->ev_tail_done));  // the copy of the results: the last thing the sum enqueued (tail stream, or its own stream for a lone short sum)
     if (e.group == PS_G1) msm_fold_host<Fp>(e.wc, pl, 0, out);
     else msm_fold_host<Fp2>(e.wc, pl, 0, out);
-    u32 entries = *(u32*)((char*)e.wc->h_pinned + e.wc->h_pinned_cap - 8);
-    c->last_info = ps_msm_info{pl.c, pl.W, entries, pl.G, pl.M};
+    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(e.wc, pl, e.group), pl.G, pl.M};
     c->last_timed = e.wc;
     return PS_OK;
 }
@@ -1243,6 +1326,11 @@ extern "C" int ps_msm_last_info(ps_ctx* c, ps_msm_info* out) {
 extern "C" int ps_msm_set_slice(ps_ctx* c, int entries) {
     if (!c || entries < 0 || entries > 4096) return fail(PS_ERR_ARG, "slice must be 0 (automatic) or 1..4096");
     c->forced_slice = entries;
+    return PS_OK;
+}
+extern "C" int ps_msm_set_tail(ps_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(PS_ERR_ARG, "tail mode must be 0 (automatic), 1 (chains) or 2 (trees)");
+    c->forced_tail = mode;
     return PS_OK;
 }
 extern "C" int ps_ctx_set_timing(ps_ctx* c, int enable) {

@@ -510,6 +510,55 @@ PS_INL Fp f_mul2add2sub(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, 
     return r;
 }
 
+// sum_k (+/-) a_k b_k under ONE Montgomery reduction -- the same column sums as f_mul / f_mul2sub / f_mul2add /
+// f_mul2add2sub, hence the same limbs bit for bit, but written for a wave that is ALONE on its SIMD (the lane-cooperative
+// additions of the short sums' tail, qtail.cuh): every column keeps its own 64-bit accumulator, so the 196 multiply-adds
+// of a product are independent of each other and the only serial chain is the 14 Montgomery digits (about five dependent
+// instructions each).  The product-scanning forms above run all 392 multiply-adds of a product through one accumulator:
+// fine when two waves share a SIMD or a thread has several products in flight, 2 x slower when neither holds (measured:
+// a quad addition 8-10 us instead of ~5).  Contract as for the fused forms: sum_k class(a_k) class(b_k) <= 8.
+template <int NPROD>
+PS_INL Fp f_mulsum_ilp(const Fp* a, const Fp* b, const bool* neg) {
+    i64 col[2 * FP_L];
+#pragma unroll
+    for (int k = 0; k < 2 * FP_L; k++) col[k] = 0;
+#pragma unroll
+    for (int q = 0; q < NPROD; q++) {
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) {
+#pragma unroll
+            for (int j = 0; j < FP_L; j++) {
+                if (neg[q]) col[i + j] -= (i64)a[q].l[i] * (i64)b[q].l[j];
+                else col[i + j] += (i64)a[q].l[i] * (i64)b[q].l[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FP_L; k++) {
+        const i32 m = (i32)(((u32)col[k] * FP_INV28) & FP_MASK);
+#pragma unroll
+        for (int j = 0; j < FP_L; j++) col[k + j] += (i64)m * (i64)fp_mod28(j);
+        col[k + 1] += col[k] >> 28;
+    }
+    Fp r;
+#pragma unroll
+    for (int k = FP_L; k < 2 * FP_L - 1; k++) {
+        r.l[k - FP_L] = (i32)((u32)col[k] & FP_MASK);
+        col[k + 1] += col[k] >> 28;
+    }
+    r.l[FP_L - 1] = (i32)col[2 * FP_L - 1];
+    return r;
+}
+PS_INL Fp f_mul_ilp(const Fp& a, const Fp& b) {
+    const bool neg[1] = {false};
+    return f_mulsum_ilp<1>(&a, &b, neg);
+}
+PS_INL Fp f_mul2sub_ilp(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {  // a b - c d
+    const Fp x[2] = {a, c}, y[2] = {b, d};
+    const bool neg[2] = {false, true};
+    return f_mulsum_ilp<2>(x, y, neg);
+}
+
 // Out-of-line copy for code paths where ten inlined multiplications per group operation would
 // not fit the instruction cache (the Fp2 tower of G2, cold exceptional cases).
 #if defined(PS_FP2_INLINE)
@@ -1039,6 +1088,18 @@ PS_INL Fp2s f_sqr(const Fp2s& a) {
 PS_INL Fp2s f_mul2sub(const Fp2s& a, const Fp2s& b, const Fp2s& c, const Fp2s& d) {
     const Fp an = f_norm(a.v), bn = f_norm(b.v), cn = f_norm(c.v), dn = f_norm(d.v);
     return Fp2s{f_mul2add2sub(an, pair_bcast0(bn), pair_cross(an), pair_bcast1(bn), cn, pair_bcast0(dn), pair_cross(cn), pair_bcast1(dn))};
+}
+// the same two forms with independent column accumulators (f_mulsum_ilp): the lane-cooperative additions of qtail.cuh
+PS_INL Fp2s f_mul_ilp(const Fp2s& a, const Fp2s& b) {
+    const Fp x[2] = {a.v, pair_cross(a.v)}, y[2] = {pair_bcast0(b.v), pair_bcast1(b.v)};
+    const bool neg[2] = {false, false};
+    return Fp2s{f_mulsum_ilp<2>(x, y, neg)};
+}
+PS_INL Fp2s f_mul2sub_ilp(const Fp2s& a, const Fp2s& b, const Fp2s& c, const Fp2s& d) {
+    const Fp an = f_norm(a.v), bn = f_norm(b.v), cn = f_norm(c.v), dn = f_norm(d.v);
+    const Fp x[4] = {an, pair_cross(an), cn, pair_cross(cn)}, y[4] = {pair_bcast0(bn), pair_bcast1(bn), pair_bcast0(dn), pair_bcast1(dn)};
+    const bool neg[4] = {false, false, true, true};
+    return Fp2s{f_mulsum_ilp<4>(x, y, neg)};
 }
 PS_INL bool f_is_zero(const Fp2s& a) {
     i32 z = f_is_zero(a.v) ? 1 : 0;

@@ -36,6 +36,10 @@ struct MsmPlan {
     int SEG;     // buckets per reduction thread
     int sets;    // bucket sets: W, or 1 when the points come with their window table 2^(c w) P (all windows share one set)
     bool table;  // the point pass reads the window table (a plain plan with a single window also has sets == 1)
+    // the tail of a short sum as trees of lane-cooperative additions (qtail.cuh) instead of chains
+    bool qtail;  // k_qfixup / k_qreduce_* instead of k_fixup / k_reduce_*
+    int lpb;     // quads per bucket in k_qfixup (0: the one-thread-per-bucket k_fixup)
+    int rc_s;    // column bits of the row / column split of a bucket set (0: bit sums straight from the buckets)
 };
 // Entries of the sorted list: point index | window << ENTRY_W_SHIFT | sign << 31.  The window field is used only
 // with a window table (then the index must fit ENTRY_W_SHIFT bits); without one the index may use all 31 bits.
@@ -820,9 +824,11 @@ __global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char
                                                        const u32* __restrict__ sorted, const u32* __restrict__ offs,
                                                        u32 G, int M, u32 idx_mask, u64 w_stride, u32 pstride,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
-                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts) {
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
+                                                       u32* __restrict__ heavy_count) {
     const u32 E = offs[G];
     const u32 t = logical_tid<KF>();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *heavy_count = 0;  // the fix-up's list of heavy buckets starts empty (no memset launch)
     const u64 start64 = (u64)t * (u64)M;
     if (start64 >= E) return;
     const u32 start = (u32)start64;
@@ -1189,14 +1195,15 @@ __global__ void __launch_bounds__(128) k_reduce_small(const Xyzz<typename FieldT
 // (window tables) the chain is 19 doublings, 50 us on the host, and the kernel is skipped.
 template <class KF>
 __global__ void __launch_bounds__(128) k_reduce_weights(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ res, u32 njobs, int small,
-                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
+                                                        int seg_log, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     typedef typename FieldTraits<KF>::Store S;
     Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
     const u32 lt = logical_local<KF>();
     Xyzz<KF> v = lt < njobs ? ld_xyzz<KF>(&res[(size_t)blockIdx.x * njobs + lt]) : xyzz_identity<KF>();
-    // results of k_reduce_small: V_j weighs 2^j; of the pyramid: A weighs 1, job j >= 1 weighs 8 * 2^(j-1)
-    const int shift = lt >= njobs ? 0 : small ? (int)lt : (lt == 0 ? 0 : (int)lt - 1 + RED_SEG_LOG);
+    // results of k_reduce_small: V_j weighs 2^j; of the pyramid: A weighs 1, job j >= 1 weighs 2^seg_log * 2^(j-1)
+    // (seg_log = RED_SEG_LOG; 0 for the [S, W_0, ..] results of k_qreduce_bits)
+    const int shift = lt >= njobs ? 0 : small ? (int)lt : (lt == 0 ? 0 : (int)lt - 1 + seg_log);
     for (int i = 0; i < shift; i++) v = xyzz_dbl_inl<KF>(v);
     block_tree_sum<KF>(sm, v);
     if (lt == 0) st_xyzz<KF>(&out[blockIdx.x], ld_xyzz<KF>(&sm[0]));
@@ -1574,3 +1581,5 @@ __global__ void __launch_bounds__(256, 1) k_fixed_base_mul(const Affine<typename
 }
 
 }  // namespace ps
+
+#include "qtail.cuh"

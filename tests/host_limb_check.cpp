@@ -88,6 +88,10 @@ static Fp random_lazy(int cls) {
 }
 static Fp reduced(const Fp& a) { return f_mul(a, fp_one()); }  // same residue, value in (-p/8, 9p/8); class(a) <= 8
 static bool same_residue(const Fp& a, const Fp& b) { return fp_all_zero(f_sub(fp_canon(reduced(a)), fp_canon(reduced(b)))); }
+static bool same_limbs(const Fp& a, const Fp& b) {  // the column-parallel forms must give the SAME limbs, not just the same residue
+    for (int i = 0; i < FP_L; i++) if (a.l[i] != b.l[i]) return false;
+    return true;
+}
 static void check_mul_output(const Fp& r, const char* what) {
     for (int i = 0; i < FP_L - 1; i++) CHECK(r.l[i] >= 0 && r.l[i] < (1 << 28), "%s: limb %d = %d outside [0, 2^28)", what, i, r.l[i]);
     CHECK(r.l[FP_L - 1] > -(1 << 25) && r.l[FP_L - 1] < (1 << 27), "%s: top limb %d", what, r.l[FP_L - 1]);
@@ -103,12 +107,14 @@ static void test_fp_products() {
                     Fp r = f_mul(a, b);
                     check_mul_output(r, "f_mul");
                     CHECK(same_residue(r, f_mul(reduced(a), reduced(b))), "f_mul classes %d x %d patterns %d %d", ca, cb, pa, pb);
+                    CHECK(same_limbs(r, f_mul_ilp(a, b)), "f_mul_ilp != f_mul, classes %d x %d patterns %d %d", ca, cb, pa, pb);
                     combos++;
                 }
     for (int it = 0; it < 2000; it++) {
         int ca = 1 + (int)(rnd() % 8), cb = 1 + (int)(rnd() % (8 / ca));
         Fp a = random_lazy(ca), b = random_lazy(cb);
         Fp r = f_mul(a, b);
+        CHECK(same_limbs(r, f_mul_ilp(a, b)), "f_mul_ilp != f_mul on random classes %d x %d", ca, cb);
         check_mul_output(r, "f_mul random");
         CHECK(same_residue(r, f_mul(reduced(a), reduced(b))), "f_mul random classes %d x %d", ca, cb);
         if (ca * ca <= 8) CHECK(same_residue(f_sqr(a), f_mul(reduced(a), reduced(a))), "f_sqr class %d", ca);
@@ -124,6 +130,12 @@ static void test_fp_products() {
                 Fp rs = f_mul2sub(a, b, c, d), ra = f_mul2add(a, b, c, d);
                 check_mul_output(rs, "f_mul2sub");
                 check_mul_output(ra, "f_mul2add");
+                CHECK(same_limbs(rs, f_mul2sub_ilp(a, b, c, d)), "f_mul2sub_ilp != f_mul2sub, class products %d + %d", c1, c2);
+                {
+                    const Fp xs[2] = {a, c}, ys[2] = {b, d};
+                    const bool plus[2] = {false, false};
+                    CHECK(same_limbs(ra, f_mulsum_ilp<2>(xs, ys, plus)), "f_mulsum_ilp<2> != f_mul2add, class products %d + %d", c1, c2);
+                }
                 CHECK(same_residue(rs, want_sub), "f_mul2sub class products %d + %d", c1, c2);
                 CHECK(same_residue(ra, want_add), "f_mul2add class products %d + %d", c1, c2);
                 combos++;
@@ -135,6 +147,11 @@ static void test_fp_products() {
         for (int k = 0; k < 4; k++) { x[2 * k] = it < 64 ? worst(cls[k], it & 3) : random_lazy(cls[k]); x[2 * k + 1] = it < 64 ? worst(1, (it >> 2) & 3) : random_lazy(1); }
         Fp r = f_mul2add2sub(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
         check_mul_output(r, "f_mul2add2sub");
+        {
+            const Fp xs[4] = {x[0], x[2], x[4], x[6]}, ys[4] = {x[1], x[3], x[5], x[7]};
+            const bool sg[4] = {false, false, true, true};
+            CHECK(same_limbs(r, f_mulsum_ilp<4>(xs, ys, sg)), "f_mulsum_ilp<4> != f_mul2add2sub, classes %d %d %d %d", cls[0], cls[1], cls[2], cls[3]);
+        }
         Fp want = f_sub(f_add(f_mul(reduced(x[0]), reduced(x[1])), f_mul(reduced(x[2]), reduced(x[3]))),
                         f_add(f_mul(reduced(x[4]), reduced(x[5])), f_mul(reduced(x[6]), reduced(x[7]))));
         CHECK(same_residue(r, want), "f_mul2add2sub classes %d %d %d %d", cls[0], cls[1], cls[2], cls[3]);

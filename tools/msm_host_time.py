@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from playsnark_amd import api
 ctx = api.Context(0)
-n = 1 << 20
+n = 1 << int(os.environ.get("LOG2N", "20"))
 a = api.Poly.upload(ctx, bench.uniform_scalars_be32(n, 1).tobytes())
 pts = api.Points.from_scalars(ctx, api.G1, a)
+if os.environ.get("TABLE", "1") == "1":
+    pts.precompute(0)
 sc = api.Poly.upload(ctx, bench.uniform_scalars_be32(n, 2).tobytes())
 for _ in range(2):
     api.msm_launch(ctx, pts, sc); api.msm_finish(ctx, api.G1)
