@@ -14,6 +14,11 @@ from . import api
 
 _WIRE = {api.G1: 96, api.G2: 192}
 
+# A one-rank group normally skips the exchange (its own partial is the result).  True runs the collective anyway -- the
+# one-rank RCCL first-contact test (tests/rccl_one_rank.py) uses it to put an RCCL communicator, the library's own HIP
+# runtime and the async all_gather_into_tensor of the pipelined runner into ONE process on the one GPU a box has.
+ALWAYS_EXCHANGE = False
+
 
 def shard_range(n: int, rank: int, world: int):
     """[first, first+count) owned by `rank`: contiguous, sizes differ by at most one."""
@@ -31,7 +36,7 @@ class ShardedMsm:
         runner keep the exchange of sum i in flight while sums i+1.. are folded: on the GPU box the RCCL kernel of a
         96-byte all_gather has to find a free CU among saturated ones, and a blocking collective per step would put that
         wait (milliseconds under load) on every step's critical path."""
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not ALWAYS_EXCHANGE):
             return partial
         import torch
 
@@ -149,7 +154,7 @@ class ShardedPHGR13:
 
     def prove(self, ek, qap, solution) -> "api.PHGR13Proof":
         mine = self.partials(ek, qap, solution)
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not ALWAYS_EXCHANGE):
             return self.fold([mine])
         import torch
 
@@ -197,7 +202,7 @@ class ShardedGroth16:
 
     def prove(self, tr, q, sol, r: int, s: int) -> "api.Groth16Proof":
         mine = self.partials(tr, q, sol, r, s)
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not ALWAYS_EXCHANGE):
             return self.fold([mine], r, s)
         import torch
 
@@ -299,7 +304,7 @@ class ShardedGroth16Local:
 
     def prove(self, tr_local, q, sol, r: int, s: int) -> "api.Groth16Proof":
         mine = self.partials(tr_local, q, sol, r, s)
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not ALWAYS_EXCHANGE):
             return ShardedGroth16.fold([mine], r, s)
         import torch
 
