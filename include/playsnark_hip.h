@@ -42,11 +42,24 @@ typedef struct ps_points ps_points;   /* device-resident point vector (a CRS arr
 typedef struct ps_scalars ps_scalars; /* device-resident Fr vector                             */
 typedef struct ps_qap ps_qap;         /* device-resident sparse QAP + per-n tables             */
 
+/* ABI revision of this header.  Structs only ever grow at the tail, and only together with this number; a caller checks
+ * ps_abi_version() == PS_ABI_VERSION once after loading the library.  Key / device structs (ps_groth16_pk, ps_phgr13_ek,
+ * ps_groth16_device, ..) MUST be zero-initialised by the caller (memset or `= {0}`): an optional array that is NULL is
+ * "not present", and garbage in a member added by a later revision would be dereferenced.
+ *   1  round 1;  2  Lagrange-form key arrays (lxi / lxi2 / lxi_t / lgsi), multi-device entries;
+ *   3  ps_msm_info.window_table, ps_msm_set_tail, ps_ctx_set_table_budget, ps_qap_is_valid, ps_microbench_mad */
+#define PS_ABI_VERSION 3
+int ps_abi_version(void);
 const char* ps_last_error(void);
 const char* ps_version(void);
 int ps_device_count(void);
 
 /* ---- context ---- */
+/* Thread safety: a ps_ctx (and the ps_qap made on it) belongs to one host thread at a time; distinct contexts may run
+ * on distinct threads concurrently, ALSO over the same ps_points / ps_scalars arrays (a key uploaded once, proved with
+ * from several threads): the arrays are read-only to the sums, their reference counts are atomic, and a window table a
+ * prover attaches on first use is built once under the array's own lock.  ps_points_precompute with another window
+ * size or -1 (release), and ps_*_free, must not race with sums over the same array. */
 int ps_ctx_create(int device, ps_ctx** out);
 void ps_ctx_destroy(ps_ctx* ctx);
 int ps_ctx_sync(ps_ctx* ctx);
@@ -78,6 +91,13 @@ int ps_points_table_window(const ps_points* p); /* window bits of the table, 0 =
  * 1024 points; cached per key; about 9 GB for a 2^20-constraint Groth16 key, 15 GB for a PHGR13 one).
  * enable = 0 keeps the provers on the plain plan. */
 int ps_ctx_set_tables(ps_ctx* ctx, int enable);
+/* Memory policy of those tables.  A prover builds a table only when it fits: `bytes` >= 0 caps ONE table (0: none fit),
+ * negative (the default) = what hipMemGetInfo reports as free, less a sixteenth of the device (at least 2 GiB) kept for
+ * the sums' own workspaces.  A table that does not fit -- or whose allocation fails -- is not an error: the sums over that
+ * array take the plain plan, which needs no memory beyond the array (ps_msm_info.window_table tells which ran), and the
+ * array is not asked again until ps_points_precompute(p, -1) clears the mark.  An explicit ps_points_precompute still
+ * fails with PS_ERR_HIP when the allocation fails. */
+int ps_ctx_set_table_budget(ps_ctx* ctx, long long bytes);
 /* *ok = 1 iff [r]P = O for every point of the array (GPU, ~400 group operations per point). */
 int ps_points_check_subgroup(ps_ctx* ctx, const ps_points* p, int* ok);
 /* out[i] = scalars[i] * G (fixed base).  GeneratePowersCommit (algebra.go:371-384) and the
@@ -155,6 +175,7 @@ typedef struct {
     uint64_t entries;  /* non-zero digits = bucket additions issued */
     uint64_t buckets;  /* W * 2^(c-1) */
     int slice;         /* sorted entries per accumulation thread */
+    int window_table;  /* 1: the sum ran over the array's window table (ps_points_precompute), 0: the plain plan */
 } ps_msm_info;
 int ps_msm_last_info(ps_ctx* ctx, ps_msm_info* out);
 int ps_msm_set_window(ps_ctx* ctx, int window_bits /* 0 = automatic, else 4..20 */);
@@ -167,6 +188,9 @@ int ps_msm_set_tail(ps_ctx* ctx, int mode);
  * run on.  Stages: 0 digits (+counter memset), 1 scan, 2 scatter, 3 queue (bucket memset, and with
  * several sums in flight the wait for the previous sum's accumulation), 4 accumulate (the dominant
  * kernel, bracketed tightly), 5 fix-up, 6 bucket reduction. */
+/* Measured issue rate of v_mad_u64_u32 (lane-operations per second, two waves per SIMD on every CU; ~1 ms): the
+ * integer roofline the bucket additions are priced against, measured on the chip and at the clocks of the run. */
+int ps_microbench_mad(ps_ctx* ctx, double* lane_mads_per_s);
 #define PS_MSM_STAGES 7
 int ps_ctx_set_timing(ps_ctx* ctx, int enable);
 int ps_msm_last_stage_ms(ps_ctx* ctx, float ms[PS_MSM_STAGES]);
@@ -187,6 +211,9 @@ void ps_qap_free(ps_qap* q);
  * each) and h (n-1 coefficients), all device-resident.  PS_ERR_NOT_DIVISIBLE <=> "apocalypse". */
 int ps_qap_quotient(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, ps_scalars** A, ps_scalars** B,
                     ps_scalars** C, ps_scalars** h);
+/* (*QAP).IsValid (qap.go:107-148): *valid = 1 iff left(x) right(x) - out(x) is divisible by z(x), i.e. iff the solution
+ * satisfies every gate.  PS_ERR_ARG <=> sanityCheck's panic (qap.go:177-189). */
+int ps_qap_is_valid(ps_ctx* ctx, const ps_qap* q, const ps_scalars* sol, int* valid);
 
 /* computeAggregatePoly (qap.go:164-175) for ONE of the three polynomials: which = 0 left (A), 1 right (B), 2 out (C);
  * n coefficients.  No divisibility test (that needs all three: ps_qap_quotient).  The three parts of the quotient --

@@ -19,15 +19,15 @@ PS_G1, PS_G2 = 1, 2
 
 # every symbol include/playsnark_hip.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "ps_last_error", "ps_version", "ps_device_count",
-    "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream", "ps_ctx_set_tables",
+    "ps_abi_version", "ps_last_error", "ps_version", "ps_device_count",
+    "ps_ctx_create", "ps_ctx_destroy", "ps_ctx_sync", "ps_ctx_stream", "ps_ctx_set_tables", "ps_ctx_set_table_budget",
     "ps_points_upload", "ps_points_from_scalars", "ps_points_download", "ps_points_download_fmt", "ps_points_len", "ps_points_group",
     "ps_points_slice", "ps_points_free", "ps_points_check_subgroup", "ps_points_precompute", "ps_points_table_window",
     "ps_scalars_upload", "ps_scalars_upload_i64", "ps_scalars_from_device_be32", "ps_scalars_download",
     "ps_scalars_len", "ps_scalars_slice", "ps_scalars_free",
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
-    "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_msm_set_tail", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
-    "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_qap_interpolate", "ps_poly_mul",
+    "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_msm_set_tail", "ps_microbench_mad", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
+    "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_qap_is_valid", "ps_qap_interpolate", "ps_poly_mul",
     "ps_points_lincomb", "ps_msm_multi_device", "ps_groth16_prove_multi",
     "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_groth16_prove_shard", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
 ]
@@ -38,7 +38,7 @@ PS_MSM_QUEUE = 3  # pending sums per context (include/playsnark_hip.h)
 
 class MsmInfo(C.Structure):
     _fields_ = [("window_bits", C.c_int), ("windows", C.c_int), ("entries", C.c_uint64),
-                ("buckets", C.c_uint64), ("slice", C.c_int)]
+                ("buckets", C.c_uint64), ("slice", C.c_int), ("window_table", C.c_int)]
 
 
 class Csr(C.Structure):
@@ -153,6 +153,9 @@ def _load():
     lib.ps_ctx_set_timing.argtypes = [vp, i]
     lib.ps_msm_set_slice.argtypes = [vp, i]
     lib.ps_msm_set_tail.argtypes = [vp, i]
+    lib.ps_microbench_mad.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.ps_ctx_set_table_budget.argtypes = [vp, C.c_longlong]
+    lib.ps_qap_is_valid.argtypes = [vp, vp, vp, C.POINTER(C.c_int)]
     lib.ps_msm_last_stage_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.ps_qap_create.argtypes = [vp, sz, sz, sz, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), pp]
     lib.ps_qap_free.argtypes = [vp]
@@ -180,3 +183,5 @@ def _load():
 
 
 lib = _load()
+if lib.ps_abi_version() != 3:  # include/playsnark_hip.h PS_ABI_VERSION: the structs above mirror that revision
+    raise ImportError("libplaysnark_hip.so has ABI %d, this binding is written for 3" % lib.ps_abi_version())

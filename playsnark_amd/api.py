@@ -77,6 +77,17 @@ class Context:
         """Whether the provers build window tables for their CRS arrays (default: yes, for keys of >= 1024 points)."""
         _check(lib.ps_ctx_set_tables(self._h, int(enable)))
 
+    def microbench_mad(self) -> float:
+        """Measured v_mad_u64_u32 issue rate in lane-operations per second (ps_microbench_mad, ~1 ms)."""
+        v = C.c_double(0.0)
+        _check(lib.ps_microbench_mad(self._h, C.byref(v)))
+        return v.value
+
+    def set_table_budget(self, nbytes: int):
+        """Bytes a prover may spend on ONE window table (negative: automatic from the free device memory); a table that
+        does not fit is skipped and the sums over that array take the plain plan."""
+        _check(lib.ps_ctx_set_table_budget(self._h, nbytes))
+
     def set_slice(self, entries: int):
         _check(lib.ps_msm_set_slice(self._h, entries))
 
@@ -445,6 +456,13 @@ class QAP:
         hs = [C.c_void_p() for _ in range(3)]
         _check(lib.ps_qap_quotient(self.ctx._h, self._h, sol._h, C.byref(hs[0]), C.byref(hs[1]), None, C.byref(hs[2])))
         return tuple(Poly(self.ctx, h) for h in hs)
+
+    def IsValid(self, sol: Poly) -> bool:
+        """func (q *QAP) IsValid(sol Vector) bool (qap.go:107): does z divide left*right - out?  (A wrong number of
+        solution variables panics in the reference's sanityCheck, qap.go:177-189: PlaysnarkError here.)"""
+        ok = C.c_int(0)
+        _check(lib.ps_qap_is_valid(self.ctx._h, self._h, sol._h, C.byref(ok)))
+        return bool(ok.value)
 
     def Quotient(self, sol: Poly) -> Poly:
         """func (q QAP) Quotient(sol Vector) Poly (qap.go:151): raises Apocalypse when the

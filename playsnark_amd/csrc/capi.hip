@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <future>
@@ -36,7 +38,8 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* ps_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* ps_version(void) { return "playsnark_hip 0.1 (gfx950)"; }
+extern "C" const char* ps_version(void) { return "playsnark_hip 0.3 (gfx950), ABI 3"; }
+extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 extern "C" int ps_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -101,6 +104,7 @@ struct ps_ctx {
     ps_ctx* last_timed = nullptr;
     float phase_ms[PS_PROVE_PHASES] = {0, 0, 0, 0};  // host wall clock of the last prover call
     bool use_tables = true;          // the provers build window tables for their CRS arrays (ps_ctx_set_tables)
+    long long table_budget = -1;     // bytes a prover may spend on ONE window table; negative: what hipMemGetInfo leaves (ps_ctx_set_table_budget)
     void* d_small = nullptr;         // 256 B of device scratch for the provers' few loose scalars (r, s, rs, 1, 0)
     hipEvent_t ev_q = nullptr;       // ordering between the context stream and the quotient's high-priority stream
     ps_msm_info last_info{};
@@ -114,6 +118,7 @@ struct ps_ctx {
     unsigned long long g16_key[4] = {0, 0, 0, 0};
     uint8_t g16_fixed[96 * 3 + 192 * 2] = {0};
     ps_points *g16_pa = nullptr, *g16_pb = nullptr, *g16_pc = nullptr;
+    bool g16_tabs = false;           // whether window tables were wanted when the arrays above were made
     hipEvent_t g16_ready = nullptr;
     // PHGR13 driver: vbs + wbs + ybs summed pointwise once per evaluation key (gz, pinochio.go:239-242)
     unsigned long long phgr_key[3] = {0, 0, 0};
@@ -129,20 +134,26 @@ struct ps_ctx {
 
 struct Storage {  // shared device allocation behind slices
     void* p = nullptr;
-    int refs = 1;
+    std::atomic<int> refs{1};  // handles (slices) on it may be made and freed by several host threads
     // Recorded by a producer that returns before its kernel has run (ps_points_from_scalars,
     // ps_scalars_from_device_be32); every stream that consumes the array waits for it first.
     hipEvent_t ready = nullptr;
-    // ps_points_precompute: window table T[w][i] = 2^(table_c * w) * P[i], w < table_W, rows of table_stride points
-    void* table = nullptr;
+    // ps_points_precompute: window table T[w][i] = 2^(table_c * w) * P[i], w < table_W, rows of table_stride points.
+    // A key shared by several contexts (one per host thread) gets its table from whichever prover comes first: built
+    // under `mu`, complete in memory before `table` is published (release), so a reader that sees the pointer (acquire)
+    // sees the geometry and may gather from it without an event.  Releasing / rebuilding with another window size is
+    // not synchronised with sums in flight on OTHER contexts: callers do that while no other thread uses the array.
+    std::mutex mu;
+    std::atomic<void*> table{nullptr};
     int table_c = 0, table_W = 0;
     size_t table_stride = 0;
+    bool table_declined = false;  // a prover found no room for it (points_ensure_table): not asked again
     size_t count = 0;  // elements in the allocation (point arrays)
 };
 static void storage_unref(Storage* s) {
-    if (s && --s->refs == 0) {
+    if (s && s->refs.fetch_sub(1) == 1) {
         if (s->ready) (void)hipEventDestroy(s->ready);
-        if (s->table) (void)hipFree(s->table);
+        if (s->table.load()) (void)hipFree(s->table.load());
         if (s->p) (void)hipFree(s->p);
         delete s;
     }
@@ -159,7 +170,7 @@ static int storage_wait_ready(const Storage* s, hipStream_t consumer) {
     return hipStreamWaitEvent(consumer, s->ready, 0) == hipSuccess ? PS_OK : PS_ERR_HIP;
 }
 
-static unsigned long long g_points_uid = 0;
+static std::atomic<unsigned long long> g_points_uid{0};
 struct ps_points {
     int group;
     size_t n;
@@ -344,7 +355,7 @@ extern "C" size_t ps_scalars_len(const ps_scalars* s) { return s ? s->n : 0; }
 extern "C" int ps_scalars_slice(const ps_scalars* s, size_t first, size_t n, ps_scalars** out) {
     if (!s || !out) return fail(PS_ERR_ARG, "ps_scalars_slice: NULL argument");
     if (first + n > s->n) return fail(PS_ERR_LENGTH, "ps_scalars_slice: range out of bounds");
-    s->st->refs++;
+    s->st->refs.fetch_add(1);
     *out = new ps_scalars{n, s->st, s->first + first, s->max_bits, s->device, s->neg_small};
     return PS_OK;
 }
@@ -419,8 +430,16 @@ extern "C" int ps_points_upload(ps_ctx* c, int group, const uint8_t* pts, size_t
 }
 
 // XYZZ -> affine for n points on c->stream (k_batch_to_affine): `tmp` holds the XYZZ points followed by the chain products.
-// (A context buffer, not hipMallocAsync: memory fresh from the stream-ordered pool lost the writes of the first kernel's
-// later workgroups on this runtime -- points 256.. of a 300-point array came back as the identity.)
+// A context buffer, not hipMallocAsync.  Round 2 saw points 256.. of a 300-point array come back as the identity with
+// staging memory from the stream-ordered pool; round 3 reproduced and isolated it (tools/malloc_async_probe.py against a
+// -DPS_AFFINE_TMP_ASYNC build, profiles/r03_malloc_async_probe.txt): allocation, both kernels and the free are on ONE
+// stream in the right order; a hipStreamSynchronize BETWEEN the kernels changes nothing; a device-to-host copy right after
+// the first kernel already shows whole workgroups' output as zeros; a hipMemsetAsync of the block before the first
+// kernel, or hipMemPoolAttrReleaseThreshold = max (freed blocks stay in the pool), makes every result right.  So: with
+// the default pool every synchronisation returns the freed block to the OS, each hipMallocAsync hands out FRESHLY MAPPED
+// memory, and on this runtime (ROCm 7.2, gfx950) the first kernel's writes to such memory are partly wiped -- consistent
+// with the clearing of new pages not being ordered before the stream's next kernel.  Not an ordering bug of this library;
+// memory that persists (this buffer) is not exposed to it.
 // Threads: at least 16 points per inversion, at most 2^16 chains.
 static size_t batch_affine_tmp_bytes(size_t n, size_t xyzz_bytes) { return n * (xyzz_bytes + sizeof(Fp)); }
 template <class F>
@@ -430,6 +449,18 @@ static void batch_to_affine(ps_ctx* c, char* tmp, size_t n, char* out, u32 out_s
                        (Fp*)(tmp + n * sizeof(Xyzz<F>)), out, out_stride);
 }
 
+#define PS_ASYNC_PROBE_SETUP \
+        const char* probe = getenv("PS_ASYNC_PROBE"); /* experiments of tools/malloc_async_probe.py */ \
+        if (probe && strchr(probe, 'r')) { /* keep freed blocks in the pool: from the second call on the memory is not fresh */ \
+            static bool once = false; \
+            if (!once) { \
+                hipMemPool_t pool; \
+                uint64_t keep = ~0ull; \
+                HIP_TRY(hipDeviceGetDefaultMemPool(&pool, c->device)); \
+                HIP_TRY(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep)); \
+                once = true; \
+            } \
+        }
 template <class F>
 static int fixed_base(ps_ctx* c, int gi, const ps_scalars* k, ps_points* out) {
     typedef typename KernelField<F>::type KF;
@@ -444,13 +475,37 @@ static int fixed_base(ps_ctx* c, int gi, const ps_scalars* k, ps_points* out) {
         c->fb_ready[gi] = true;
     }
     if (k->n) {
+#if defined(PS_AFFINE_TMP_ASYNC)  // the variant round 2 dropped (stream-ordered staging memory), kept for tools/malloc_async_probe.py
+        char* tmp = nullptr;
+        PS_ASYNC_PROBE_SETUP
+        HIP_TRY(hipMallocAsync((void**)&tmp, batch_affine_tmp_bytes(k->n, sizeof(Xyzz<F>)), c->stream));
+#else
         int rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(k->n, sizeof(Xyzz<F>)));
         if (rc) return rc;
         char* tmp = (char*)c->affine_tmp.p;
+#endif
+#if defined(PS_AFFINE_TMP_ASYNC)
+        if (probe && strchr(probe, 'm')) HIP_TRY(hipMemsetAsync(tmp, 0, batch_affine_tmp_bytes(k->n, sizeof(Xyzz<F>)), c->stream));
+#endif
         hipLaunchKernelGGL(k_fixed_base_mul<KF>, dim3(nblocks(k->n * LN)), dim3(256), 0, c->stream,
                            (const Affine<F>*)c->fb_table[gi].p, scalars_ptr(k), (u32)k->n, (Xyzz<F>*)tmp);
+#if defined(PS_AFFINE_TMP_ASYNC)
+        if (probe && strchr(probe, 's')) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (probe && strchr(probe, 'd')) {  // what did the first kernel leave in memory?  (copy engine's view)
+            std::vector<Xyzz<F>> host(k->n);
+            HIP_TRY(hipMemcpyAsync(host.data(), tmp, sizeof(Xyzz<F>) * k->n, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            size_t zero = 0, first = k->n;
+            for (size_t i = 0; i < k->n; i++)
+                if (fp_all_zero(host[i].zz)) { zero++; if (first == k->n) first = i; }
+            fprintf(stderr, "[probe] after k_fixed_base_mul: %zu of %zu points have ZZ == 0 in memory (first %zu), tmp = %p\n", zero, (size_t)k->n, first, (void*)tmp);
+        }
+#endif
         batch_to_affine<F>(c, tmp, k->n, (char*)out->st->p, (u32)sizeof(Affine<F>));
         HIP_TRY(hipGetLastError());
+#if defined(PS_AFFINE_TMP_ASYNC)
+        HIP_TRY(hipFreeAsync(tmp, c->stream));
+#endif
     }
     return PS_OK;
 }
@@ -522,7 +577,7 @@ extern "C" int ps_points_group(const ps_points* p) { return p ? p->group : 0; }
 extern "C" int ps_points_slice(const ps_points* p, size_t first, size_t n, ps_points** out) {
     if (!p || !out) return fail(PS_ERR_ARG, "ps_points_slice: NULL argument");
     if (first + n > p->n) return fail(PS_ERR_LENGTH, "ps_points_slice: range out of bounds");
-    p->st->refs++;
+    p->st->refs.fetch_add(1);
     *out = new ps_points{p->group, n, p->st, p->first + first, p->device};
     return PS_OK;
 }
@@ -551,12 +606,12 @@ static int table_window_for(size_t n) {
     return best;
 }
 template <class F>
-static int build_table(ps_ctx* c, Storage* st, int group, int wbits, int W) {
+static int build_table(ps_ctx* c, Storage* st, void* table, int group, int wbits, int W) {
     typedef typename KernelField<F>::type KF;
     constexpr unsigned LN = FieldTraits<KF>::LANES;
     const size_t n = st->count;
     const u32 rb = (u32)table_row_bytes(group);
-    char* tab = (char*)st->table;
+    char* tab = (char*)table;
     hipLaunchKernelGGL(k_table_row0<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<F>*)st->p, tab, rb, (u32)n);
     if (W > 1) {
         int rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(n, sizeof(Xyzz<F>)));
@@ -571,44 +626,87 @@ static int build_table(ps_ctx* c, Storage* st, int group, int wbits, int W) {
     HIP_TRY(hipGetLastError());
     return PS_OK;
 }
+// Room for a table of `bytes`?  Within the context's budget (ps_ctx_set_table_budget; negative = automatic) and leaving a
+// sixteenth of the device, at least 2 GiB, for the workspaces of the sums themselves (buckets, sort buffers).
+static bool table_fits(const ps_ctx* c, size_t bytes) {
+    if (c->table_budget >= 0 && bytes > (size_t)c->table_budget) return false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const size_t reserve = std::max<size_t>(total_b / 16, (size_t)2 << 30);
+    return bytes + reserve <= free_b;
+}
+// The table of the allocation behind `p` for `window_bits` (0 = automatic), built once whoever asks first.
+// optional: a prover's request -- no room (budget, free memory, or hipMalloc failing) is not an error: the array is marked
+// and the sums over it take the plain plan.  Returns with the table complete in memory (the context stream is waited for).
+static int points_ensure_table(ps_ctx* c, const ps_points* p, int window_bits, bool optional) {
+    Storage* st = p->st;
+    const size_t n = st->count;
+    if (n == 0) return PS_OK;
+    if (n >= (1ull << ENTRY_W_SHIFT)) {
+        if (optional) return PS_OK;
+        return fail(PS_ERR_ARG, "ps_points_precompute: at most 2^26 - 1 points per array (split it with ps_points_slice before uploading)");
+    }
+    const int wbits = window_bits ? window_bits : table_window_for(n);
+    if (st->table.load(std::memory_order_acquire) && st->table_c == wbits) return PS_OK;
+    std::lock_guard<std::mutex> lock(st->mu);
+    if (st->table.load(std::memory_order_acquire) && st->table_c == wbits) return PS_OK;  // another context built it meanwhile
+    if (optional && (st->table_declined || st->table.load())) return PS_OK;  // asked before / the caller's own table stays
+    const int W = 255 / wbits + 1;
+    const size_t bytes = table_row_bytes(p->group) * n * (size_t)W;
+    const size_t work = batch_affine_tmp_bytes(n, p->group == PS_G1 ? sizeof(Xyzz<Fp>) : sizeof(Xyzz<Fp2>));
+    if (optional && !table_fits(c, bytes + (c->affine_tmp.cap >= work ? 0 : work))) {
+        st->table_declined = true;
+        return PS_OK;
+    }
+    if (storage_wait_ready(st, c->stream)) return fail(PS_ERR_HIP, "ps_points_precompute: event wait failed");
+    if (void* old = st->table.load()) {  // another window size: sums of THIS process that may still read the old table are waited for
+        HIP_TRY(hipDeviceSynchronize());
+        st->table.store(nullptr, std::memory_order_release);
+        (void)hipFree(old);
+    }
+    void* tab = nullptr;
+    hipError_t e = hipMalloc(&tab, bytes);
+    int rc = PS_OK;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rc = fail(PS_ERR_HIP, std::string("hipMalloc window table: ") + hipGetErrorString(e));
+    } else {
+        rc = p->group == PS_G1 ? build_table<Fp>(c, st, tab, PS_G1, wbits, W) : build_table<Fp2>(c, st, tab, PS_G2, wbits, W);
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(PS_ERR_HIP, "ps_points_precompute: building the table failed");
+        if (rc) (void)hipFree(tab);
+    }
+    if (rc) {
+        if (!optional) return rc;
+        st->table_declined = true;  // no room after all (e.g. the staging buffer): the plain plan needs no extra memory
+        g_last_error.clear();
+        return PS_OK;
+    }
+    st->table_c = wbits;
+    st->table_W = W;
+    st->table_stride = n;
+    st->table.store(tab, std::memory_order_release);
+    return PS_OK;
+}
 extern "C" int ps_points_precompute(ps_ctx* c, ps_points* p, int window_bits) {
     if (!c || !p) return fail(PS_ERR_ARG, "ps_points_precompute: NULL argument");
     if (window_bits == -1) {  // release
         Storage* st0 = p->st;
-        if (!st0->table) return PS_OK;
+        std::lock_guard<std::mutex> lock(st0->mu);
+        void* old = st0->table.load();
+        st0->table_declined = false;
+        if (!old) return PS_OK;
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(st0->table);
-        st0->table = nullptr;
+        st0->table.store(nullptr, std::memory_order_release);
+        (void)hipFree(old);
         st0->table_c = st0->table_W = 0;
         return PS_OK;
     }
     if (window_bits != 0 && (window_bits < 8 || window_bits > 22)) return fail(PS_ERR_ARG, "ps_points_precompute: window bits must be 0 (automatic), -1 (release) or 8..22");
-    Storage* st = p->st;
-    const size_t n = st->count;
-    if (n == 0) return PS_OK;
-    if (n >= (1ull << ENTRY_W_SHIFT)) return fail(PS_ERR_ARG, "ps_points_precompute: at most 2^26 - 1 points per array (split it with ps_points_slice before uploading)");
     HIP_TRY(hipSetDevice(c->device));
-    const int wbits = window_bits ? window_bits : table_window_for(n);
-    if (st->table && st->table_c == wbits) return PS_OK;
-    if (storage_wait_ready(st, c->stream)) return fail(PS_ERR_HIP, "ps_points_precompute: event wait failed");
-    if (st->table) {  // another window size: sums that may still read the old table are waited for
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(st->table);
-        st->table = nullptr;
-    }
-    const int W = 255 / wbits + 1;
-    hipError_t e = hipMalloc(&st->table, table_row_bytes(p->group) * n * (size_t)W);
-    if (e != hipSuccess) { st->table = nullptr; return fail(PS_ERR_HIP, std::string("hipMalloc window table: ") + hipGetErrorString(e)); }
-    int rc = p->group == PS_G1 ? build_table<Fp>(c, st, PS_G1, wbits, W) : build_table<Fp2>(c, st, PS_G2, wbits, W);
-    if (!rc && storage_mark_ready(st, c->stream)) rc = fail(PS_ERR_HIP, "ps_points_precompute: event record failed");
-    if (rc) { (void)hipStreamSynchronize(c->stream); (void)hipFree(st->table); st->table = nullptr; return rc; }
-    st->table_c = wbits;
-    st->table_W = W;
-    st->table_stride = n;
-    return PS_OK;
+    return points_ensure_table(c, p, window_bits, false);
 }
-extern "C" int ps_points_table_window(const ps_points* p) { return p && p->st->table ? p->st->table_c : 0; }
+extern "C" int ps_points_table_window(const ps_points* p) { return p && p->st->table.load(std::memory_order_acquire) ? p->st->table_c : 0; }
 
 // Every point of the array in the order-r subgroup?  ([r]P on the device: ~400 group operations per point;
 // an opt-in check for arrays that arrive from outside -- ps_points_upload itself only tests the curve equation.)
@@ -869,7 +967,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const u32 per_role = rp.m * (u32)pl.sets, nres = rp.njobs * (u32)pl.sets;
     const bool tab = pl.table;
     const u32 pstride = tab ? (u32)table_row_bytes(pts->group) : (u32)sizeof(Affine<F>);
-    const char* src = tab ? (const char*)pts->st->table + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
+    const char* src = tab ? (const char*)pts->st->table.load(std::memory_order_acquire) + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
     const u32 idx_mask = tab ? (1u << ENTRY_W_SHIFT) - 1u : 0x7fffffffu;
     const u64 w_stride = tab ? (u64)pts->st->table_stride : 0ull;
     int rc;
@@ -900,10 +998,13 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         st = wc->tail;   // ---- the rest runs on the high-priority tail stream ----
         HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
     }
-    if (pl.qtail && pl.lpb >= 1)
-        hipLaunchKernelGGL(k_qfixup<KF>, dim3(nblocks(G * (u64)pl.lpb * QTraits<KF>::GL)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
-                           (u32)pl.lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
-    else
+    if (pl.qtail && pl.lpb >= 1) {
+        // the plan of a multi-sum is shared by arrays of both groups (PHGR13: six G1 sums and a G2 one over one sort): the
+        // quads of a bucket must fit THIS group's 256-thread block (64 G1 points, 32 G2 points)
+        const u32 lpb = std::min<u32>((u32)pl.lpb, 256 / QTraits<KF>::GL);
+        hipLaunchKernelGGL(k_qfixup<KF>, dim3(nblocks(G * (u64)lpb * QTraits<KF>::GL)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
+                           lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
+    } else
     hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                        (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     {
@@ -977,7 +1078,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
 static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int max_bits) {
     const Storage* st = pts->st;
     // a forced window size means "the plain path with this c" (A/B runs); entries keep 26 bits for the index
-    return st->table && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
+    return st->table.load(std::memory_order_acquire) && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
 }
 // Short sums (fewer than PS_QTAIL_MAX_ENTRIES digits): the chip is mostly idle behind the accumulation and the sum's time
 // is the depth of its dependency chain, so the tail runs as trees of lane-cooperative additions (qtail.cuh) and the slices
@@ -1034,9 +1135,12 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
         const double cost_plain = (double)n * plain.W * 10.0 + (double)plain.G * 42.0;
         if (cost_plain < PS_TABLE_COST_MARGIN * cost_tab) pl = plain;
     }
-    msm_plan_tail(pl, n, k ? pts[0]->group : PS_G1, c->forced_tail, c->q_len > 0);
+    int plan_group = PS_G1;  // the group the tail is sized for: G2 as soon as one array of the call is (its points take twice the lanes)
+    for (size_t i = 0; i < k; i++)
+        if (pts[i]->group == PS_G2) plan_group = PS_G2;
+    msm_plan_tail(pl, n, plan_group, c->forced_tail, c->q_len > 0);
     if (c->forced_slice) pl.M = c->forced_slice;
-    if (pl.qtail) msm_plan_lpb(pl, n, k ? pts[0]->group : PS_G1);
+    if (pl.qtail) msm_plan_lpb(pl, n, plan_group);
     if ((u64)pl.W * (u64)n >= (1ull << 32))
         return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +
                                     " digits do not fit the 32-bit sort offsets (split the sum, e.g. ps_points_slice)");
@@ -1174,7 +1278,7 @@ static int msm_multi_finish(ps_ctx* c, ps_ctx* w0, const ps_points* const* pts, 
         if (pts[i]->group == PS_G1) msm_fold_host<Fp>(w0, pl, (int)i, out[i]);
         else msm_fold_host<Fp2>(w0, pl, (int)i, out[i]);
     }
-    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(w0, pl, pts[0]->group), pl.G, pl.M};
+    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(w0, pl, pts[0]->group), pl.G, pl.M, pl.table ? 1 : 0};
     return PS_OK;
 }
 
@@ -1291,7 +1395,7 @@ extern "C" int ps_msm_finish(ps_ctx* c, uint8_t* out) {
     HIP_TRY(hipEventSynchronize(e.wc->ev_tail_done));  // the copy of the results: the last thing the sum enqueued (tail stream, or its own stream for a lone short sum)
     if (e.group == PS_G1) msm_fold_host<Fp>(e.wc, pl, 0, out);
     else msm_fold_host<Fp2>(e.wc, pl, 0, out);
-    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(e.wc, pl, e.group), pl.G, pl.M};
+    c->last_info = ps_msm_info{pl.c, pl.W, msm_entries(e.wc, pl, e.group), pl.G, pl.M, pl.table ? 1 : 0};
     c->last_timed = e.wc;
     return PS_OK;
 }
@@ -1358,6 +1462,55 @@ extern "C" int ps_prove_last_phase_ms(ps_ctx* c, float* ms) {
 extern "C" int ps_ctx_set_tables(ps_ctx* c, int enable) {
     if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
     c->use_tables = enable != 0;
+    return PS_OK;
+}
+// Issue rate of the multiplier the bucket additions are bound by: v_mad_u64_u32, eight independent chains per lane, two
+// waves per SIMD on every CU (the recipe of tools/microbench_valu.hip), timed with HIP events on the context stream.
+// ~1 ms; bench.py calls it so that the roofline's integer peak is measured in the same run, on the same chip and clocks.
+__global__ void __launch_bounds__(256) k_microbench_mad(unsigned long long* out, u32 seed, int iters) {
+    const u32 a = (seed * (threadIdx.x + 1)) | 1u, b = (seed ^ (threadIdx.x * 2654435761u)) | 1u;
+    unsigned long long acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[c] = a + c;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+        }
+    }
+    unsigned long long s = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) s += acc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+extern "C" int ps_microbench_mad(ps_ctx* c, double* lane_mads_per_s) {
+    if (!c || !lane_mads_per_s) return fail(PS_ERR_ARG, "ps_microbench_mad: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * 2, iters = 2048;  // 256 threads = one wave per SIMD: two waves per SIMD
+    int rc = c->staging.ensure(sizeof(unsigned long long) * 256 * (size_t)blocks);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double best = 0;
+    for (int rep = 0; rep < 3; rep++) {  // the first repetition also warms the clocks up
+        HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+        hipLaunchKernelGGL(k_microbench_mad, dim3(blocks), dim3(256), 0, c->stream, (unsigned long long*)c->staging.p, 12345u + rep, iters);
+        HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        HIP_TRY(hipEventSynchronize(c->ev[1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        const double ops = (double)iters * 64.0 * 256.0 * blocks;
+        if (ms > 0) best = std::max(best, ops / (ms * 1e-3));
+    }
+    c->ev_valid = false;
+    *lane_mads_per_s = best;
+    return PS_OK;
+}
+extern "C" int ps_ctx_set_table_budget(ps_ctx* c, long long bytes) {
+    if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
+    c->table_budget = bytes;
     return PS_OK;
 }
 extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {

@@ -11,8 +11,9 @@
 // decompression on the GPU; ps_point_convert on the few proof elements that come back).
 //
 // The image this library is built in has no Go toolchain, so this file is source only (SURVEY.md
-// 8 row f4); every C entry point it calls is exercised by tests/abi_smoke.c (plain C) and by the
-// ctypes binding the test-suite runs on.
+// 8 row f4) and has never been compiled or vetted: do that first (`go vet -tags hip`) wherever Go is available.
+// Every C entry point it calls -- the multi-device ones included -- is exercised by tests/abi_smoke.c (plain C) and by
+// the ctypes binding the test-suite runs on.
 package playsnark
 
 /*
@@ -26,6 +27,8 @@ import "C"
 
 import (
 	"fmt"
+	"runtime"
+	"sync"
 	"unsafe"
 
 	"github.com/drand/kyber/util/random"
@@ -35,24 +38,61 @@ import (
 // context and error mapping
 // ---------------------------------------------------------------------------------------
 
-var hipCtx *C.ps_ctx
+// The reference's Groth16Prove / PHGR13Prove / BlindEval are pure functions that any number of goroutines may call.
+// A ps_ctx is NOT thread-safe (one stream, one workspace, one queue of pending sums), so every use of the package
+// context is serialised by hipMu.  (A pool of contexts -- one per caller, all over the same uploaded key arrays, which
+// the library allows: include/playsnark_hip.h "Thread safety" -- is the way to prove from several goroutines at once.)
+var (
+	hipCtx *C.ps_ctx
+	hipMu  sync.Mutex
+)
 
 func init() {
+	if v := int(C.ps_abi_version()); v != C.PS_ABI_VERSION {
+		panic(fmt.Sprintf("playsnark_hip: library ABI %d, shim written for %d", v, C.PS_ABI_VERSION))
+	}
+	runtime.LockOSThread() // ps_last_error is thread-local: read it on the thread that made the failing call
+	defer runtime.UnlockOSThread()
 	if rc := C.ps_ctx_create(0, &hipCtx); rc != C.PS_OK {
 		// no CPU fallback behind this build tag: fail as loudly as the reference's own panics
 		panic("playsnark_hip: " + C.GoString(C.ps_last_error()))
 	}
 }
 
-// check maps the C error codes onto the reference's panics.
-func check(rc C.int) {
+// call runs one library call that uses hipCtx: under the context's lock, and pinned to its OS thread so that
+// ps_last_error() (thread-local in the library) is read on the thread the failing call ran on -- a goroutine may
+// otherwise be rescheduled onto another thread between two cgo calls.  Error codes map onto the reference's panics.
+func call(f func() C.int) {
+	hipMu.Lock()
+	runtime.LockOSThread()
+	rc := f()
+	msg := ""
+	if rc != C.PS_OK {
+		msg = C.GoString(C.ps_last_error())
+	}
+	runtime.UnlockOSThread()
+	hipMu.Unlock()
 	switch rc {
 	case C.PS_OK:
 	case C.PS_ERR_NOT_DIVISIBLE:
 		panic("apocalypse") // qap.go:159, pinochio.go:215
 	default:
 		// PS_ERR_LENGTH carries the message of algebra.go:351, PS_ERR_ARG that of sanityCheck (qap.go:177-189)
-		panic(C.GoString(C.ps_last_error()))
+		panic(msg)
+	}
+}
+
+// check is `call` for the entry points that touch no context (ps_point_convert, ps_points_sum, ..).
+func check(f func() C.int) {
+	runtime.LockOSThread()
+	rc := f()
+	msg := ""
+	if rc != C.PS_OK {
+		msg = C.GoString(C.ps_last_error())
+	}
+	runtime.UnlockOSThread()
+	if rc != C.PS_OK {
+		panic(msg)
 	}
 }
 
@@ -110,14 +150,14 @@ func affineOf(group C.int, p Commit) []byte {
 		panic(err)
 	}
 	out := make([]byte, wireLen(group))
-	check(C.ps_point_convert(group, C.PS_FMT_COMPRESSED, C.PS_FMT_AFFINE, u8(in), u8(out)))
+	check(func() C.int { return C.ps_point_convert(group, C.PS_FMT_COMPRESSED, C.PS_FMT_AFFINE, u8(in), u8(out)) })
 	return out
 }
 
 // pointFrom turns an affine result of the library back into a kyber point of the group of `like`.
 func pointFrom(group C.int, affine []byte, like Commit) Commit {
 	comp := make([]byte, wireLen(group)/2)
-	check(C.ps_point_convert(group, C.PS_FMT_AFFINE, C.PS_FMT_COMPRESSED, u8(affine), u8(comp)))
+	check(func() C.int { return C.ps_point_convert(group, C.PS_FMT_AFFINE, C.PS_FMT_COMPRESSED, u8(affine), u8(comp)) })
 	p := like.Clone()
 	if err := p.UnmarshalBinary(comp); err != nil {
 		panic(err)
@@ -134,7 +174,7 @@ func copyTo(dst unsafe.Pointer, src []byte) {
 func uploadPoints(group C.int, pts []Commit) *C.ps_points {
 	raw := marshalPoints(pts)
 	var h *C.ps_points
-	check(C.ps_points_upload(hipCtx, group, u8(raw), C.size_t(len(pts)), C.PS_FMT_COMPRESSED, &h))
+	call(func() C.int { return C.ps_points_upload(hipCtx, group, u8(raw), C.size_t(len(pts)), C.PS_FMT_COMPRESSED, &h) })
 	return h
 }
 
@@ -149,14 +189,14 @@ func uploadSolution(sol Vector) *C.ps_scalars {
 	if len(vals) > 0 {
 		p = &vals[0]
 	}
-	check(C.ps_scalars_upload_i64(hipCtx, p, C.size_t(len(vals)), &h))
+	call(func() C.int { return C.ps_scalars_upload_i64(hipCtx, p, C.size_t(len(vals)), &h) })
 	return h
 }
 
 func downloadPoly(h *C.ps_scalars) Poly {
 	n := int(C.ps_scalars_len(h))
 	raw := make([]byte, 32*n)
-	check(C.ps_scalars_download(hipCtx, h, 0, C.size_t(n), u8(raw)))
+	call(func() C.int { return C.ps_scalars_download(hipCtx, h, 0, C.size_t(n), u8(raw)) })
 	out := make(Poly, n)
 	for i := range out {
 		e := NewElement()
@@ -197,7 +237,7 @@ func (p Poly) BlindEvalHIP(zero Commit, crs *C.ps_points) Commit {
 	group := C.ps_points_group(crs)
 	sc := marshalScalars(p)
 	out := make([]byte, wireLen(group))
-	check(C.ps_msm_be32(hipCtx, crs, u8(sc), C.size_t(len(p)), u8(out)))
+	call(func() C.int { return C.ps_msm_be32(hipCtx, crs, u8(sc), C.size_t(len(p)), u8(out)) })
 	return pointFrom(group, out, zero)
 }
 
@@ -205,11 +245,11 @@ func (p Poly) BlindEvalHIP(zero Commit, crs *C.ps_points) Commit {
 func (p Poly) MulHIP(p2 Poly) Poly {
 	var a, b, prod *C.ps_scalars
 	ra, rb := marshalScalars(p), marshalScalars(p2)
-	check(C.ps_scalars_upload(hipCtx, u8(ra), C.size_t(len(p)), &a))
+	call(func() C.int { return C.ps_scalars_upload(hipCtx, u8(ra), C.size_t(len(p)), &a) })
 	defer C.ps_scalars_free(a)
-	check(C.ps_scalars_upload(hipCtx, u8(rb), C.size_t(len(p2)), &b))
+	call(func() C.int { return C.ps_scalars_upload(hipCtx, u8(rb), C.size_t(len(p2)), &b) })
 	defer C.ps_scalars_free(b)
-	check(C.ps_poly_mul(hipCtx, a, b, &prod))
+	call(func() C.int { return C.ps_poly_mul(hipCtx, a, b, &prod) })
 	defer C.ps_scalars_free(prod)
 	return downloadPoly(prod)
 }
@@ -278,7 +318,7 @@ func NewHipQAP(circuit R1CS) *HipQAP {
 	defer r.free()
 	defer o.free()
 	q := &HipQAP{nbVars: len(circuit.vars), nbIO: circuit.nbIO(), nbGates: len(circuit.left)}
-	check(C.ps_qap_create(hipCtx, C.size_t(q.nbGates), C.size_t(q.nbVars), C.size_t(q.nbIO), &l.csr, &r.csr, &o.csr, &q.h))
+	call(func() C.int { return C.ps_qap_create(hipCtx, C.size_t(q.nbGates), C.size_t(q.nbVars), C.size_t(q.nbIO), &l.csr, &r.csr, &o.csr, &q.h) })
 	return q
 }
 
@@ -290,9 +330,19 @@ func (q *HipQAP) QuotientHIP(sol Vector) Poly {
 	dsol := uploadSolution(sol)
 	defer C.ps_scalars_free(dsol)
 	var h *C.ps_scalars
-	check(C.ps_qap_quotient(hipCtx, q.h, dsol, nil, nil, nil, &h))
+	call(func() C.int { return C.ps_qap_quotient(hipCtx, q.h, dsol, nil, nil, nil, &h) })
 	defer C.ps_scalars_free(h)
 	return downloadPoly(h)
+}
+
+// IsValidHIP replaces `func (q *QAP) IsValid(sol Vector) bool` (qap.go:107-148): does z(x) divide
+// left(x) right(x) - out(x)?  On the device: the three SpMVs and the gate check of the quotient.
+func (q *HipQAP) IsValidHIP(sol Vector) bool {
+	dsol := uploadSolution(sol)
+	defer C.ps_scalars_free(dsol)
+	var ok C.int
+	call(func() C.int { return C.ps_qap_is_valid(hipCtx, q.h, dsol, &ok) })
+	return ok != 0
 }
 
 // ---------------------------------------------------------------------------------------
@@ -350,7 +400,7 @@ func NewHipGroth16FromToxicWaste(tr Groth16Setup, q *HipQAP) *HipGroth16 {
 	put(&tw.x[0], tr.tw.X)
 	put(&tw.gamma[0], tr.tw.Gamma)
 	var crs C.ps_groth16_crs
-	check(C.ps_groth16_setup(hipCtx, q.h, &tw, &crs))
+	call(func() C.int { return C.ps_groth16_setup(hipCtx, q.h, &tw, &crs) })
 	hs := &HipGroth16{qap: q, xi: crs.xi, xi2: crs.xi2, nioLP: crs.nio_lp, xiT: crs.xi_t, ioLP: crs.io_lp}
 	hs.lagrange = []*C.ps_points{crs.lxi, crs.lxi2, crs.lxi_t}
 	hs.pk.alpha, hs.pk.beta, hs.pk.delta, hs.pk.beta2, hs.pk.delta2 = crs.alpha, crs.beta, crs.delta, crs.beta2, crs.delta2
@@ -380,7 +430,7 @@ func Groth16ProveHIP(hs *HipGroth16, sol Vector) Groth16Proof {
 	A := make([]byte, g1Wire)
 	B := make([]byte, g2Wire)
 	Cc := make([]byte, g1Wire)
-	check(C.ps_groth16_prove(hipCtx, &hs.pk, hs.qap.h, dsol, u8(rb), u8(sb), u8(A), u8(B), u8(Cc)))
+	call(func() C.int { return C.ps_groth16_prove(hipCtx, &hs.pk, hs.qap.h, dsol, u8(rb), u8(sb), u8(A), u8(B), u8(Cc)) })
 	return Groth16Proof{
 		tp: groth16ToxicProof{R: r, S: s},
 		A:  pointFrom(C.PS_G1, A, zeroG1),
@@ -396,9 +446,200 @@ func Groth16VerifyHIP(hs *HipGroth16, p Groth16Proof, io Vector) bool {
 	dio := uploadSolution(io)
 	defer C.ps_scalars_free(dio)
 	var ok C.int
-	check(C.ps_groth16_verify(hipCtx, &hs.vk, dio, u8(affineOf(C.PS_G1, p.A)), u8(affineOf(C.PS_G2, p.B)),
-		u8(affineOf(C.PS_G1, p.C)), &ok))
+	call(func() C.int { return C.ps_groth16_verify(hipCtx, &hs.vk, dio, u8(affineOf(C.PS_G1, p.A)), u8(affineOf(C.PS_G2, p.B)),
+		u8(affineOf(C.PS_G1, p.C)), &ok) })
 	return ok != 0
+}
+
+// ---------------------------------------------------------------------------------------
+// Several GPUs from ONE process (a cgo caller cannot wrap a function call in one process per GPU, which is how
+// bench.py and playsnark_amd/dist.py scale): ps_msm_multi_device and ps_groth16_prove_multi run one context per
+// device side by side and fold the per-device partial sums on the host (SURVEY.md 8e, DESIGN.md section 7).
+// ---------------------------------------------------------------------------------------
+
+// shardRange is the index range [first, first+count) of device d of ndev: contiguous, sizes differ by at most one
+// (the split ps_groth16_prove_multi checks with PS_ERR_LENGTH).
+func shardRange(n, d, ndev int) (int, int) {
+	base, extra := n/ndev, n%ndev
+	first := d*base + minInt(d, extra)
+	if d < extra {
+		return first, base + 1
+	}
+	return first, base
+}
+
+func minInt(a, b int) int {
+	if a < b {
+		return a
+	}
+	return b
+}
+
+// HipDevices is one context per GPU of this process.
+type HipDevices struct {
+	mu   sync.Mutex
+	ctxs []*C.ps_ctx
+}
+
+func NewHipDevices(ndev int) *HipDevices {
+	hd := &HipDevices{}
+	for d := 0; d < ndev; d++ {
+		var c *C.ps_ctx
+		check(func() C.int { return C.ps_ctx_create(C.int(d), &c) })
+		hd.ctxs = append(hd.ctxs, c)
+	}
+	return hd
+}
+
+func (hd *HipDevices) Free() {
+	for _, c := range hd.ctxs {
+		C.ps_ctx_destroy(c)
+	}
+}
+
+// HipShardedPoints is a CRS slice cut by index range over the devices (device d holds shardRange(len, d, ndev)).
+type HipShardedPoints struct {
+	parts []*C.ps_points
+	n     int
+}
+
+func (hd *HipDevices) UploadPoints(group C.int, pts []Commit) *HipShardedPoints {
+	sp := &HipShardedPoints{n: len(pts)}
+	for d, c := range hd.ctxs {
+		first, cnt := shardRange(len(pts), d, len(hd.ctxs))
+		raw := marshalPoints(pts[first : first+cnt])
+		var h *C.ps_points
+		cc := c
+		check(func() C.int { return C.ps_points_upload(cc, group, u8(raw), C.size_t(cnt), C.PS_FMT_COMPRESSED, &h) })
+		sp.parts = append(sp.parts, h)
+	}
+	return sp
+}
+
+func (sp *HipShardedPoints) Free() {
+	for _, p := range sp.parts {
+		C.ps_points_free(p)
+	}
+}
+
+// BlindEvalHIPMulti is Poly.BlindEval (algebra.go:348-359) with the sum sharded over the devices.
+func (p Poly) BlindEvalHIPMulti(zero Commit, hd *HipDevices, crs *HipShardedPoints) Commit {
+	if crs.n != len(p) { // algebra.go:350-352
+		panic(fmt.Sprintf("mismatch of length between poly %d and blinded eval points %d", len(p), crs.n))
+	}
+	hd.mu.Lock()
+	defer hd.mu.Unlock()
+	ndev := len(hd.ctxs)
+	scal := make([]*C.ps_scalars, ndev)
+	for d, c := range hd.ctxs {
+		first, cnt := shardRange(len(p), d, ndev)
+		raw := marshalScalars(p[first : first+cnt])
+		cc, dd := c, d
+		check(func() C.int { return C.ps_scalars_upload(cc, u8(raw), C.size_t(cnt), &scal[dd]) })
+		defer C.ps_scalars_free(scal[d])
+	}
+	group := C.ps_points_group(crs.parts[0])
+	out := make([]byte, wireLen(group))
+	// the three pointer arrays live in C memory (cgo: no Go pointers to Go pointers across the boundary)
+	arr := func(n int) unsafe.Pointer { return C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))) }
+	cctx, cpts, csc := arr(ndev), arr(ndev), arr(ndev)
+	defer C.free(cctx)
+	defer C.free(cpts)
+	defer C.free(csc)
+	for d := 0; d < ndev; d++ {
+		(*[1 << 20]*C.ps_ctx)(cctx)[d] = hd.ctxs[d]
+		(*[1 << 20]*C.ps_points)(cpts)[d] = crs.parts[d]
+		(*[1 << 20]*C.ps_scalars)(csc)[d] = scal[d]
+	}
+	check(func() C.int {
+		return C.ps_msm_multi_device((**C.ps_ctx)(cctx), (**C.ps_points)(cpts), (**C.ps_scalars)(csc), C.size_t(ndev), u8(out))
+	})
+	return pointFrom(group, out, zero)
+}
+
+// HipGroth16Multi: every device holds only ITS index range of Xi, Xi2, NioLP, XiT (an eighth of the key on eight GPUs),
+// its own QAP of the circuit and its own copy of the solution.
+type HipGroth16Multi struct {
+	hd     *HipDevices
+	dev    []C.ps_groth16_device
+	qaps   []*C.ps_qap
+	arrays []*HipShardedPoints
+}
+
+func NewHipGroth16Multi(hd *HipDevices, tr Groth16Setup, circuit R1CS) *HipGroth16Multi {
+	hm := &HipGroth16Multi{hd: hd, dev: make([]C.ps_groth16_device, len(hd.ctxs))} // zero-initialised, as the header requires
+	xi, xi2 := hd.UploadPoints(C.PS_G1, tr.Xi), hd.UploadPoints(C.PS_G2, tr.Xi2)
+	nio, xit := hd.UploadPoints(C.PS_G1, tr.NioLP), hd.UploadPoints(C.PS_G1, tr.XiT)
+	hm.arrays = []*HipShardedPoints{xi, xi2, nio, xit}
+	l, r, o := newCsr(circuit.left), newCsr(circuit.right), newCsr(circuit.out)
+	defer l.free()
+	defer r.free()
+	defer o.free()
+	for d, c := range hd.ctxs {
+		var q *C.ps_qap
+		cc := c
+		check(func() C.int {
+			return C.ps_qap_create(cc, C.size_t(len(circuit.left)), C.size_t(len(circuit.vars)), C.size_t(circuit.nbIO()), &l.csr, &r.csr, &o.csr, &q)
+		})
+		hm.qaps = append(hm.qaps, q)
+		hm.dev[d].ctx, hm.dev[d].qap = c, q
+		pk := &hm.dev[d].pk
+		pk.xi, pk.xi2, pk.nio_lp, pk.xi_t = xi.parts[d], xi2.parts[d], nio.parts[d], xit.parts[d]
+		if d == 0 { // the fixed points are read from dev[0].pk
+			copyTo(unsafe.Pointer(&pk.alpha[0]), affineOf(C.PS_G1, tr.Alpha))
+			copyTo(unsafe.Pointer(&pk.beta[0]), affineOf(C.PS_G1, tr.Beta))
+			copyTo(unsafe.Pointer(&pk.delta[0]), affineOf(C.PS_G1, tr.Delta))
+			copyTo(unsafe.Pointer(&pk.beta2[0]), affineOf(C.PS_G2, tr.Beta2))
+			copyTo(unsafe.Pointer(&pk.delta2[0]), affineOf(C.PS_G2, tr.Delta2))
+		}
+	}
+	return hm
+}
+
+func (hm *HipGroth16Multi) Free() {
+	for _, q := range hm.qaps {
+		C.ps_qap_free(q)
+	}
+	for _, a := range hm.arrays {
+		a.Free()
+	}
+}
+
+// Groth16ProveHIPMulti is Groth16Prove (groth16.go:122-211) over the devices of this process: same proof bytes as
+// Groth16ProveHIP for the same (r, s).
+func Groth16ProveHIPMulti(hm *HipGroth16Multi, sol Vector) Groth16Proof {
+	r := NewElement().Pick(random.New())
+	s := NewElement().Pick(random.New())
+	rb, _ := r.MarshalBinary()
+	sb, _ := s.MarshalBinary()
+	hm.hd.mu.Lock()
+	defer hm.hd.mu.Unlock()
+	vals := make([]C.int64_t, len(sol))
+	for i, v := range sol {
+		vals[i] = C.int64_t(v)
+	}
+	// the device structs go to C memory: they hold C pointers only, but live in a Go slice
+	cdev := (*C.ps_groth16_device)(C.malloc(C.size_t(len(hm.dev)) * C.size_t(unsafe.Sizeof(hm.dev[0]))))
+	defer C.free(unsafe.Pointer(cdev))
+	devs := (*[1 << 16]C.ps_groth16_device)(unsafe.Pointer(cdev))[:len(hm.dev):len(hm.dev)]
+	for d := range hm.dev {
+		var h *C.ps_scalars
+		cc := hm.dev[d].ctx
+		check(func() C.int { return C.ps_scalars_upload_i64(cc, &vals[0], C.size_t(len(vals)), &h) })
+		defer C.ps_scalars_free(h)
+		devs[d] = hm.dev[d]
+		devs[d].sol = h
+	}
+	A, B, Cc := make([]byte, g1Wire), make([]byte, g2Wire), make([]byte, g1Wire)
+	check(func() C.int {
+		return C.ps_groth16_prove_multi(cdev, C.size_t(len(hm.dev)), u8(rb), u8(sb), u8(A), u8(B), u8(Cc))
+	})
+	return Groth16Proof{
+		tp: groth16ToxicProof{R: r, S: s},
+		A:  pointFrom(C.PS_G1, A, zeroG1),
+		B:  pointFrom(C.PS_G2, B, zeroG2),
+		C:  pointFrom(C.PS_G1, Cc, zeroG1),
+	}
 }
 
 // ---------------------------------------------------------------------------------------
@@ -452,7 +693,7 @@ func PHGR13ProveHIP(hp *HipPHGR13, solution Vector) PHGR13Proof {
 	dsol := uploadSolution(solution)
 	defer C.ps_scalars_free(dsol)
 	var out C.ps_phgr13_proof
-	check(C.ps_phgr13_prove(hipCtx, &hp.ek, hp.qap.h, dsol, &out))
+	call(func() C.int { return C.ps_phgr13_prove(hipCtx, &hp.ek, hp.qap.h, dsol, &out) })
 	g1 := func(p *C.uint8_t) Commit { return pointFrom(C.PS_G1, bytesOf(unsafe.Pointer(p), g1Wire), zeroG1) }
 	return PHGR13Proof{
 		vss:  g1(&out.vss[0]),
@@ -481,7 +722,7 @@ func PHGR13VerifyHIP(hp *HipPHGR13, p PHGR13Proof, io Vector) bool {
 	dio := uploadSolution(io)
 	defer C.ps_scalars_free(dio)
 	var ok C.int
-	check(C.ps_phgr13_verify(hipCtx, &hp.vk, dio, &in, &ok))
+	call(func() C.int { return C.ps_phgr13_verify(hipCtx, &hp.vk, dio, &in, &ok) })
 	return ok != 0
 }
 
@@ -496,4 +737,7 @@ func PHGR13VerifyHIP(hp *HipPHGR13, p PHGR13Proof, io Vector) bool {
 //	require.True(t, Groth16VerifyHIP(hs, proof, s[:qap.nbVars-qap.nbIO]))      // or the library's
 //	setup := NewPHGR13TrustedSetup(qap); hp := NewHipPHGR13(setup, hq)
 //	require.True(t, PHGR13Verify(setup.VK, qap, PHGR13ProveHIP(hp, s), s[:qap.nbVars-qap.nbIO]))
+//	require.True(t, hq.IsValidHIP(s))                                            // TestQAPValidity, qap_test.go
+//	hd := NewHipDevices(8); hm := NewHipGroth16Multi(hd, tr, r1cs)              // one process, eight GPUs
+//	require.True(t, Groth16Verify(tr, qap, Groth16ProveHIPMulti(hm, s), s[:qap.nbVars-qap.nbIO]))
 // ---------------------------------------------------------------------------------------

@@ -59,6 +59,8 @@ static const uint8_t* get(const char* name, size_t want_len) {
 int main(int argc, char** argv) {
     if (argc < 2 || load_fixture(argv[1])) { fprintf(stderr, "usage: abi_smoke fixture.txt\n"); return 1; }
     printf("%s, %d device(s)\n", ps_version(), ps_device_count());
+    CHECK(ps_abi_version() == PS_ABI_VERSION); /* the library was built from THIS header revision */
+    CHECK(sizeof(ps_msm_info) == 32 && sizeof(ps_groth16_pk) == 3 * 96 + 2 * 192 + 7 * sizeof(void*));
     ps_ctx* ctx = NULL;
     int rc = ps_ctx_create(0, &ctx);
     if (rc == PS_ERR_NO_DEVICE) { printf("no gfx950 device: %s\n", ps_last_error()); return 77; }
@@ -147,10 +149,73 @@ int main(int argc, char** argv) {
     uint8_t out2[96];
     CHECK(ps_msm(ctx, xit, h, out2) == PS_OK && !memcmp(out, out2, 96));
 
+    /* (*QAP).IsValid, qap.go:107-148 */
+    int valid = -1;
+    CHECK(ps_qap_is_valid(ctx, qap, sol, &valid) == PS_OK && valid == 1);
+    CHECK(ps_qap_is_valid(ctx, qap, bad, &valid) == PS_OK && valid == 0);
+    ps_msm_info info;
+    CHECK(ps_msm_last_info(ctx, &info) == PS_OK && info.windows > 0 && info.window_table == 0);
+
+    /* ---- the in-process multi-device entries, as a cgo caller uses them (shim/playsnark_hip.go: BlindEvalHIPMulti,
+     * Groth16ProveHIPMulti), here with two contexts on device 0.  Device d holds ITS index range of every array. ---- */
+    {
+        ps_ctx* ctx2 = NULL;
+        CHECK(ps_ctx_create(0, &ctx2) == PS_OK);
+        ps_ctx* ctxs[2];
+        ctxs[0] = ctx; ctxs[1] = ctx2;
+        /* h . XiT over two shards: XiT[0..2) on context 0, XiT[2..3) on context 1 (sizes differ by at most one) */
+        ps_points *xit0 = NULL, *xit1 = NULL;
+        ps_scalars *h0s = NULL, *h1s = NULL;
+        uint8_t hraw[3 * 32];
+        CHECK(ps_scalars_download(ctx, h, 0, 3, hraw) == PS_OK);
+        CHECK(ps_points_upload(ctx, PS_G1, get("XiT", 3 * 96), 2, PS_FMT_AFFINE, &xit0) == PS_OK);
+        CHECK(ps_points_upload(ctx2, PS_G1, get("XiT", 3 * 96) + 2 * 96, 1, PS_FMT_AFFINE, &xit1) == PS_OK);
+        CHECK(ps_scalars_upload(ctx, hraw, 2, &h0s) == PS_OK && ps_scalars_upload(ctx2, hraw + 64, 1, &h1s) == PS_OK);
+        const ps_points* mp[2];
+        const ps_scalars* ms[2];
+        mp[0] = xit0; mp[1] = xit1; ms[0] = h0s; ms[1] = h1s;
+        uint8_t out3[96];
+        CHECK(ps_msm_multi_device(ctxs, mp, ms, 2, out3) == PS_OK && !memcmp(out3, out, 96));
+
+        /* Groth16Prove over rank-local keys: Xi, Xi2 (4 points) 2 + 2; NioLP, XiT (3 points) 2 + 1 */
+        ps_groth16_device dev[2];
+        memset(dev, 0, sizeof dev); /* the header requires zero-initialised structs */
+        ps_qap* qap2 = NULL;
+        ps_scalars* sol2 = NULL;
+        CHECK(ps_qap_create(ctx2, 4, 6, 3, &L, &R, &O, &qap2) == PS_OK);
+        CHECK(ps_scalars_upload_i64(ctx2, witness, 6, &sol2) == PS_OK);
+        ps_points* part[2][4];
+        for (int d = 0; d < 2; d++) {
+            ps_ctx* cd = ctxs[d];
+            const size_t f4 = d ? 2 : 0, n4 = 2, f3 = d ? 2 : 0, n3 = d ? 1 : 2;
+            CHECK(ps_points_upload(cd, PS_G1, get("Xi", 4 * 96) + f4 * 96, n4, PS_FMT_AFFINE, &part[d][0]) == PS_OK);
+            CHECK(ps_points_upload(cd, PS_G2, get("Xi2", 4 * 192) + f4 * 192, n4, PS_FMT_AFFINE, &part[d][1]) == PS_OK);
+            CHECK(ps_points_upload(cd, PS_G1, get("NioLP", 3 * 96) + f3 * 96, n3, PS_FMT_AFFINE, &part[d][2]) == PS_OK);
+            CHECK(ps_points_upload(cd, PS_G1, get("XiT", 3 * 96) + f3 * 96, n3, PS_FMT_AFFINE, &part[d][3]) == PS_OK);
+            dev[d].ctx = cd;
+            dev[d].qap = d ? qap2 : qap;
+            dev[d].sol = d ? sol2 : sol;
+            dev[d].pk.xi = part[d][0]; dev[d].pk.xi2 = part[d][1]; dev[d].pk.nio_lp = part[d][2]; dev[d].pk.xi_t = part[d][3];
+        }
+        memcpy(dev[0].pk.alpha, pk.alpha, 96); memcpy(dev[0].pk.beta, pk.beta, 96); memcpy(dev[0].pk.delta, pk.delta, 96);
+        memcpy(dev[0].pk.beta2, pk.beta2, 192); memcpy(dev[0].pk.delta2, pk.delta2, 192);
+        uint8_t A2[96], B2[192], C2[96];
+        CHECK(ps_groth16_prove_multi(dev, 2, get("r", 32), get("s", 32), A2, B2, C2) == PS_OK);
+        CHECK(!memcmp(A2, get("A", 96), 96) && !memcmp(B2, get("B", 192), 192) && !memcmp(C2, get("C", 96), 96));
+        /* a key that is not cut at the index ranges is refused, as BlindEval's length panic */
+        dev[1].pk.xi_t = part[1][0]; /* 2 points where device 1 must hold 1 */
+        CHECK(ps_groth16_prove_multi(dev, 2, get("r", 32), get("s", 32), A2, B2, C2) == PS_ERR_LENGTH);
+        for (int d = 0; d < 2; d++)
+            for (int k = 0; k < 4; k++) ps_points_free(part[d][k]);
+        ps_points_free(xit0); ps_points_free(xit1); ps_scalars_free(h0s); ps_scalars_free(h1s); ps_scalars_free(sol2);
+        ps_qap_free(qap2);
+        ps_ctx_destroy(ctx2);
+    }
+
     ps_scalars_free(h); ps_scalars_free(bad); ps_scalars_free(io); ps_scalars_free(gam); ps_scalars_free(sol);
     ps_points_free(gam_pt); ps_points_free(xi); ps_points_free(xi2); ps_points_free(nio); ps_points_free(xit); ps_points_free(iolp);
     ps_qap_free(qap);
     ps_ctx_destroy(ctx);
-    printf("abi_smoke ok: toy Groth16 proof equals the golden fixture, verifies, and the error codes map the reference's panics\n");
+    printf("abi_smoke ok: toy Groth16 proof equals the golden fixture (one context, and two contexts over rank-local keys), verifies, and the error codes map the reference's panics\n");
     return 0;
 }

@@ -756,3 +756,33 @@ def test_tail_of_a_sum_chains_and_trees_give_the_oracle_bytes(ps_api, ctx, co, p
     finally:
         ctx.set_tail(0)
         ctx.set_slice(0)
+
+
+@pytest.mark.parametrize("n,table", [(2047, True), (2047, False), (300, True), (9000, True)])
+def test_multi_sum_over_both_groups_shares_one_tail_plan(ps_api, ctx, co, pr, n, table):
+    """computeSolCommit's sums (pinochio.go:231-241) go through ps_msm_multi: ONE digit sort and ONE plan for arrays of
+    both groups (PHGR13: ws is G2).  The tree tail sizes its fix-up by lanes per point, which differ between the groups
+    (4 / 8): a plan sized for the G1 arrays once put 64 quads of a bucket into a G2 block that holds 32 -- the G2 element of
+    a 2^11-constraint PHGR13 proof came back as zeros (round 3, found by the two-thread prover test).  Chains and trees,
+    with skewed scalars (many slices per bucket), against the oracle."""
+    rng = _rng(pr, 5200 + n)
+    kinds = ["g1", "g2", "g1"]
+    raws, pts = [], []
+    for name in kinds:
+        gid, og = _grp(ps_api, co, name)
+        raw = og.gen_points(rng.fr(), rng.fr(), n)
+        p = ps_api.Points.upload(ctx, gid, raw)
+        if table:
+            p.precompute(0)
+        raws.append(raw)
+        pts.append(p)
+    try:
+        for sc in ([rng.fr() for _ in range(n)], [int(rng.next() & 1) for _ in range(n)], [rng.fr()] * n):
+            dsc = ps_api.Poly.upload(ctx, sc)
+            want = [_grp(ps_api, co, name)[1] for name in kinds]
+            want = [og.to_b(og.msm_pippenger(co.pack_fr(sc), raw, n, 4)) for og, raw in zip(want, raws)]
+            for mode in (1, 2, 0):
+                ctx.set_tail(mode)
+                assert ps_api.msm_multi(ctx, pts, dsc) == want, (n, table, mode)
+    finally:
+        ctx.set_tail(0)

@@ -531,3 +531,120 @@ def test_aggregate_polynomials_and_h_byte_exact_at_2pow16(ps_api, ctx, co, pr):
         assert g == w, name
     assert q.Quotient(dsol).download_bytes() == want[3]      # the h-only route
     assert q.interpolate(dsol, 1).download_bytes() == want[1]  # one polynomial alone
+
+
+def test_qap_is_valid_is_the_reference_divisibility_test(ps_api, ctx, pr):
+    """(*QAP).IsValid (qap.go:107-148, TestQAPValidity qap_test.go): true for the toy witness and the tiled circuit's
+    solution, false once any wire value is off by one; a wrong number of variables is sanityCheck's panic."""
+    from oracle import restate as rs
+
+    c, wit = rs.toy_circuit()
+    q = _upload_circuit(ps_api, ctx, c)
+    assert q.IsValid(ps_api.Poly.from_values(ctx, wit)) is True
+    for i in range(1, len(wit)):
+        bad = list(wit)
+        bad[i] += 1
+        assert q.IsValid(ps_api.Poly.from_values(ctx, bad)) is False, i
+    c, sol = rs.synthetic_circuit(300)
+    q = _upload_circuit(ps_api, ctx, c)
+    assert q.IsValid(ps_api.Poly.upload(ctx, sol)) is True
+    sol[17] = (sol[17] + 1) % pr.R
+    assert q.IsValid(ps_api.Poly.upload(ctx, sol)) is False
+    with pytest.raises(ps_api.PlaysnarkError):
+        q.IsValid(ps_api.Poly.upload(ctx, sol[:-1]))
+
+
+def test_one_key_two_contexts_two_threads_same_proof(ps_api, co, pr):
+    """A proving key uploaded once and used from two host threads, each with its own context and QAP, as the reference's
+    pure Groth16Prove / PHGR13Prove allow (groth16.go:122, pinochio.go:207): the window tables the provers attach to the
+    key's arrays on first use are built once, under the array's lock (prove.inc mutated the caller's key
+    through const, unsynchronised).  Both threads race into the first proof; every proof must be the oracle's."""
+    import threading
+
+    from oracle import restate as rs
+
+    n = 2048  # keys of >= 1024 points get tables
+    c, sol = rs.synthetic_circuit(n)
+    c.nbIO = c.nbVars - 3  # the reference's split diff = nbVars - nbIO after (const, x, out): ~n witness values in the prover's sums
+    rng = pr.SplitMix64(SEED + 909)
+    tw = [rng.fr() for _ in range(5)]
+    tw8 = [rng.fr() for _ in range(8)]
+    r, s = rng.fr(), rng.fr()
+    ctx0 = ps_api.Context(0)
+    q0 = _upload_circuit(ps_api, ctx0, c)
+    tr, _vk = ps_api.NewGroth16TrustedSetup(q0, *tw)
+    ek, _pvk = ps_api.NewPHGR13TrustedSetup(q0, *tw8)
+    tr_mono = tr.monomial_only()
+    ctx0.sync()
+    want = rs.groth16_prove(rs.groth16_setup(c, *tw), c, sol, r, s, fast=True)
+    want_p = rs.phgr13_prove(rs.phgr13_setup(c, *tw8).EK, c, sol, fast=True)
+    errors, barrier = [], threading.Barrier(2)
+
+    def worker(tid):
+        try:
+            cx = ps_api.Context(0)
+            q = _upload_circuit(ps_api, cx, c)
+            dsol = ps_api.Poly.upload(cx, sol)
+            barrier.wait()
+            for rep in range(4):
+                for key in (tr, tr_mono):
+                    got = ps_api.Groth16Prove(key, q, dsol, r, s)
+                    assert (got.A, got.B, got.C) == (want.A, want.B, want.C), ("groth16", tid, rep)
+                gp = ps_api.PHGR13Prove(ek, q, dsol)
+                for f in ps_api.PHGR13Proof.FIELDS:
+                    assert getattr(gp, f) == getattr(want_p, f), ("phgr13", tid, rep, f)
+            cx.close()
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert ek.vs.table_window > 0  # the shared evaluation key did get its tables, once
+    ctx0.close()
+
+
+def test_tables_that_do_not_fit_fall_back_to_the_plain_plan(ps_api, co, pr):
+    """Memory policy of the provers' window tables (VERDICT r2 / ADVICE): with a budget too small for a table (here forced
+    through ps_ctx_set_table_budget; by default what hipMemGetInfo leaves) the first proof does not fail with PS_ERR_HIP --
+    the sums run the plain plan (ps_msm_info.window_table == 0), the arrays are not asked again, and the proof bytes are
+    those of the table plan."""
+    from oracle import restate as rs
+
+    n = 2048
+    c, sol = rs.synthetic_circuit(n)
+    c.nbIO = c.nbVars - 3
+    rng = pr.SplitMix64(SEED + 910)
+    tw, tw8 = [rng.fr() for _ in range(5)], [rng.fr() for _ in range(8)]
+    r, s = rng.fr(), rng.fr()
+    want = rs.groth16_prove(rs.groth16_setup(c, *tw), c, sol, r, s, fast=True)
+    want_p = rs.phgr13_prove(rs.phgr13_setup(c, *tw8).EK, c, sol, fast=True)
+    for budget, expect_table in ((4096, 0), (-1, 1)):
+        cx = ps_api.Context(0)
+        cx.set_table_budget(budget)
+        q = _upload_circuit(ps_api, cx, c)
+        dsol = ps_api.Poly.upload(cx, sol)
+        tr, _vk = ps_api.NewGroth16TrustedSetup(q, *tw)
+        ek, _pvk = ps_api.NewPHGR13TrustedSetup(q, *tw8)
+        for _ in range(2):
+            got = ps_api.Groth16Prove(tr, q, dsol, r, s)
+            assert (got.A, got.B, got.C) == (want.A, want.B, want.C)
+            assert cx.last_msm_info()["window_table"] == expect_table
+            gp = ps_api.PHGR13Prove(ek, q, dsol)
+            for f in ps_api.PHGR13Proof.FIELDS:
+                assert getattr(gp, f) == getattr(want_p, f), f
+            assert cx.last_msm_info()["window_table"] == expect_table
+        assert (ek.vs.table_window > 0) == bool(expect_table)
+        # an explicit request is still honoured (and still an error when it cannot be)
+        if not expect_table:
+            ek.vs.precompute(-1)   # clears the "declined" mark
+            ek.vs.precompute(0)
+            assert ek.vs.table_window > 0
+        cx.close()
