@@ -1519,5 +1519,13 @@ extern "C" int ps_msm_set_window(ps_ctx* c, int bits) {
     return PS_OK;
 }
 
+#if defined(PS_NTT_TUNE)  // measurement builds only (tools/ntt_phases.py): the phase stamps of the traced NTT pass
+extern "C" int ps_debug_ntt_trace(unsigned long long* out, int* meta) {
+    if (!g_ntt_trace_buf) return PS_ERR_ARG;
+    for (int i = 0; i < 6; i++) meta[i] = g_ntt_trace_meta[i];
+    HIP_TRY(hipMemcpy(out, g_ntt_trace_buf, 4 * 8192 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PS_OK;
+}
+#endif
 #include "prove.inc"
 #include "pairing.inc"

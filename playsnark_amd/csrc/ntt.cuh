@@ -82,11 +82,18 @@ struct NttFuse {
 // __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Four 256-thread workgroups
 // per CU (two of 512 with the 80 KB tile) need 4 waves per SIMD, i.e. at most 128 VGPRs; with "2" the inverse pass took 139 and ran one workgroup per CU
 // (measured: no difference in the quotient's time either way -- the passes are bound by their instruction count).
+#if defined(PS_NTT_TUNE)
+__device__ unsigned long long* ntt_trace = nullptr;  // 4 timestamps (s_memtime, 100 MHz) per workgroup of the traced launch
+#define PS_NTT_STAMP(i) do { if (ntt_trace && threadIdx.x == 0) ntt_trace[4 * (size_t)blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PS_NTT_STAMP(i) do { } while (0)
+#endif
 template <bool INV>
 __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
                                                   const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
+    PS_NTT_STAMP(0);
     const u32 COLS = 1u << logCols, rows = 1u << k;
     const u32 tile_elems = rows << logCols;
     const u64 q0 = (u64)blockIdx.x << logCols;
@@ -114,6 +121,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         tile[t * COLS + col] = v;
     }
     __syncthreads();
+    PS_NTT_STAMP(1);
     // global index of element (row t, column col) of this tile, and the twiddle of the butterfly block
     // that holds global index i at a stage with half-distance 2^logh (returns false when w = 1)
     auto gidx = [&](u32 t, u32 col) -> u64 {
@@ -199,6 +207,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
     // The inverse doubles along the all-sums path (a product pulls a value back under 2r, a sum does not);
     // 2^16 r still fits the lazy limbs with room to spare (top limb < 2^20), so ntt_run asks for the
     // scaling 2^-scale_log only in the last pass of a transform, or earlier for very long ones.
+    PS_NTT_STAMP(2);
     Fr sc;
     if (INV && scale_log) {
 #pragma unroll
@@ -223,8 +232,177 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
             fz.st_dst[fz.st == NTT_ST_TAKE ? addr : fz.top - addr] = v;
         }
     }
+    PS_NTT_STAMP(3);
 }
 
+#if defined(PS_NTT_PASS8)
+// ---- MEASURED AND NOT SHIPPED (round 3): the same pass with the data in REGISTERS, -DPS_NTT_PASS8 ----
+// Eight elements per thread, three butterfly stages per LDS round trip: 320 instructions per butterfly instead of 450 --
+// and 6 % SLOWER on the quotient (A/B on one box, tools/ntt_ab.sh: 11.6-12.0 ms against 10.9-11.1).  A pass is not bound by
+// its instruction count alone: with one round of workgroups the chip loads, computes and stores in lock-step, so a
+// 2^20-element pass costs ~12 us + ~18 us of memory phase + 3.5 us per stage, added up (without its butterflies the pass
+// still takes 32-46 us, tools/ntt_tune.sh with -DPS_NTT8_SKIP_BF), and what hides one phase under another is waves per
+// SIMD: this kernel holds 172 / 218 VGPRs (two waves per SIMD), k_ntt_pass 128 (four).  Prefetching the next tile into
+// registers from a persistent loop made it worse (in-order vmcnt: the first twiddle load waits for the prefetch).  Kept
+// behind the switch as the record of the experiment; DESIGN.md section 6.
+// k_ntt_pass above spends 450 instructions per butterfly for the 250 of its field product: a round trip through LDS and
+// the index arithmetic of a four-row group every two stages, a carry-save step behind every butterfly, one twiddle load
+// per butterfly pair.  Here a thread holds the eight elements that differ in three consecutive stage bits (a "window"
+// of the tile's element index), runs the three stages on them in registers -- 12 butterflies, 7 twiddles, one carry-save
+// step per element and window (the forward transform only adds products: limb class 1 + 3 <= 7; the inverse, whose sums
+// double, normalises once more inside the window) -- and meets the other threads in LDS only between windows.  The first
+// window is loaded straight from HBM and the last one stored straight to it, so a pass of k stages makes ceil(k/3) - 1
+// LDS round trips instead of k/2, and a 2^21-point transform is 9 + 6 + 6 stages with four of them in all.
+// Tile element index: bits [logL, logL + k) are the row (stage) bits, logL = min(logD, logCols), so that consecutive
+// elements are consecutive in HBM whichever way the pass strides.
+PS_INL Fr ntt_ld(const Fr* __restrict__ data, u64 addr, const NttFuse& fz) {
+    if (fz.ld == NTT_LD_PLAIN) return data[addr];
+    if (fz.ld == NTT_LD_UPPER_HALF) {
+        const u64 half = 1ull << (fz.logs - 1);
+        return (addr & (2 * half - 1)) < half ? fz.ld_src[addr + half] : fr_zero();
+    }
+    if (fz.ld == NTT_LD_SCALE_PAD) return addr < fz.cnt ? fr_mul(fz.ld_src[addr], fz.ld_aux[addr]) : fr_zero();
+    if (fz.ld == NTT_LD_PAD) return addr < fz.cnt ? fz.ld_src[addr] : fr_zero();
+    return addr < fz.cnt ? fz.ld_src[fz.top - addr] : fr_zero();
+}
+PS_INL void ntt_st(Fr* __restrict__ data, u64 addr, const Fr& v, const NttFuse& fz) {
+    if (fz.st == NTT_ST_PLAIN) {
+        data[addr] = v;
+    } else if (fz.st == NTT_ST_MUL) {
+        data[addr] = fr_mul(v, fz.st_aux[addr]);
+    } else if (fz.st == NTT_ST_COMBINE) {
+        const u64 half = 1ull << (fz.logs - 1);
+        fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
+    } else if (addr < fz.cnt) {
+        fz.st_dst[fz.st == NTT_ST_TAKE ? addr : fz.top - addr] = v;
+    }
+}
+
+// one butterfly, Cooley-Tukey (a + w b, a - w b) forward, Gentleman-Sande (a + b, (a - b) w) inverse
+template <bool INV>
+__device__ inline __attribute__((always_inline)) void ntt8_bf(Fr& a, Fr& b, const Fr& w, bool has_w) {
+    if (!INV) {
+        const Fr wb = has_w ? fr_mul(b, w) : b;
+        b = fr_sub(a, wb);
+        a = fr_add(a, wb);
+    } else {
+        const Fr d = fr_sub(a, b);
+        a = fr_add(a, b);
+        b = has_w ? fr_mul(d, w) : d;
+    }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(256, 2) k_ntt_pass8(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+                                                      const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
+    extern __shared__ __align__(16) unsigned char ntt_smem[];
+    Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
+    const u32 tid = threadIdx.x;
+    const int logL = logD < logCols ? logD : logCols;
+    const u64 q0 = (u64)blockIdx.x << logCols;
+    const u64 Dm1 = (1ull << logD) - 1, smask = (1ull << p) - 1;
+    const u32 rmask = (1u << k) - 1u, lmask = (1u << logL) - 1u;
+    auto gaddr_at = [&](u32 e, u64 qbase) -> u64 {  // HBM index of element e of the tile whose first column is qbase
+        const u32 t = (e >> logL) & rmask, col = ((e >> (logL + k)) << logL) | (e & lmask);
+        const u64 q = qbase + col;
+        return ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
+    };
+    auto gaddr = [&](u32 e) -> u64 { return gaddr_at(e, q0); };
+    // twiddle of the butterfly block that holds HBM index `a` at the stage of row bit m (false: the single block of a
+    // transform's outermost stage, w = 1)
+    auto twiddle = [&](u64 a, int m, Fr& w) -> bool {
+        const int logh = logD + m, M = p - 1 - logh;
+        if (M <= 0) return false;
+        const u32 blk = (u32)((a & smask) >> (logh + 1));
+        w = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
+        return true;
+    };
+    PS_NTT_STAMP(0);
+    const int ngroups = k >= 3 ? (k + 2) / 3 : 1;
+    // eight named values, not an array: every index below is a literal, so they stay in registers (an Fr x[8] walked by
+    // loops inside the window loop went to scratch: 336 bytes, a hundred scratch stores per pass)
+    Fr x0, x1, x2, x3, x4, x5, x6, x7;
+#define PS_NTT8_EACH(OP) OP(x0, 0) OP(x1, 1) OP(x2, 2) OP(x3, 3) OP(x4, 4) OP(x5, 5) OP(x6, 6) OP(x7, 7)
+    for (int gi = 0; gi < ngroups; gi++) {
+        // window [mwin, mwin + 3) of row bits and the stages [m_lo, m_hi] it runs (forward: downwards)
+        int mwin, m_lo, m_hi;
+        if (k < 3) { mwin = 0; m_lo = 0; m_hi = k - 1; }
+        else if (!INV) { m_hi = k - 1 - 3 * gi; m_lo = m_hi - 2 < 0 ? 0 : m_hi - 2; mwin = m_lo; }
+        else { m_lo = 3 * gi; m_hi = m_lo + 2 > k - 1 ? k - 1 : m_lo + 2; mwin = m_lo + 3 <= k ? m_lo : k - 3; }
+        const int pos = logL + mwin;
+        const u32 base = ((tid >> pos) << (pos + 3)) | (tid & ((1u << pos) - 1u));
+        if (gi == 0) {
+#define PS_NTT8_LDG(X, J) X = ntt_ld(data, gaddr(base | ((u32)(J) << pos)), fz);
+            PS_NTT8_EACH(PS_NTT8_LDG)
+#undef PS_NTT8_LDG
+        } else {
+#define PS_NTT8_LDS(X, J) X = tile[base | ((u32)(J) << pos)];
+            PS_NTT8_EACH(PS_NTT8_LDS)
+#undef PS_NTT8_LDS
+        }
+        // the (up to) three stages of the window; the stage of window bit s pairs the elements whose numbers differ in bit s,
+        // and the elements of a pair share their block's twiddle with every pair that agrees with them above bit s
+        Fr w;
+        bool hw;
+        auto tw_of = [&](int j0, int m) -> bool { return twiddle(gaddr(base | ((u32)j0 << pos)), m, w); };
+        const bool do0 = mwin >= m_lo && mwin <= m_hi, do1 = mwin + 1 >= m_lo && mwin + 1 <= m_hi, do2 = mwin + 2 >= m_lo && mwin + 2 <= m_hi;
+#define PS_NTT8_S2 { hw = tw_of(0, mwin + 2); ntt8_bf<INV>(x0, x4, w, hw); ntt8_bf<INV>(x1, x5, w, hw); ntt8_bf<INV>(x2, x6, w, hw); ntt8_bf<INV>(x3, x7, w, hw); }
+#define PS_NTT8_S1 { hw = tw_of(0, mwin + 1); ntt8_bf<INV>(x0, x2, w, hw); ntt8_bf<INV>(x1, x3, w, hw); \
+                     hw = tw_of(4, mwin + 1); ntt8_bf<INV>(x4, x6, w, hw); ntt8_bf<INV>(x5, x7, w, hw); }
+#define PS_NTT8_S0 { hw = tw_of(0, mwin); ntt8_bf<INV>(x0, x1, w, hw); hw = tw_of(2, mwin); ntt8_bf<INV>(x2, x3, w, hw); \
+                     hw = tw_of(4, mwin); ntt8_bf<INV>(x4, x5, w, hw); hw = tw_of(6, mwin); ntt8_bf<INV>(x6, x7, w, hw); }
+#if defined(PS_NTT8_SKIP_BF)  // measurement build: the pass without its butterflies (what the memory phases alone cost)
+        (void)do0; (void)do1; (void)do2; (void)hw; (void)tw_of;
+        if (false)
+#endif
+        if (!INV) {
+            if (do2) PS_NTT8_S2
+            if (do1) PS_NTT8_S1
+            if (do0) PS_NTT8_S0
+        } else {
+            if (do0) PS_NTT8_S0
+            if (do1) PS_NTT8_S1
+            if (do2) {
+                // two stages of sums may lie behind us: limb class 4, the next sum would not fit an i32 limb
+#define PS_NTT8_NORM(X, J) X = fr_norm(X);
+                PS_NTT8_EACH(PS_NTT8_NORM)
+                PS_NTT8_S2
+            }
+        }
+#undef PS_NTT8_S0
+#undef PS_NTT8_S1
+#undef PS_NTT8_S2
+        if (gi + 1 < ngroups) {
+            // a thread writes the slots it read itself (windows partition the tile): one barrier, before the NEXT window's reads
+#define PS_NTT8_STS(X, J) tile[base | ((u32)(J) << pos)] = fr_norm(X);
+            PS_NTT8_EACH(PS_NTT8_STS)
+#undef PS_NTT8_STS
+            __syncthreads();
+            if (gi == 0) PS_NTT_STAMP(1);
+        } else {
+            PS_NTT_STAMP(2);
+            Fr sc;
+            if (INV && scale_log) {
+#pragma unroll
+                for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[scale_log][j];
+            }
+#define PS_NTT8_STG(X, J) { Fr v = fr_norm(X); if (INV && scale_log) v = fr_mul(v, sc); ntt_st(data, gaddr(base | ((u32)(J) << pos)), v, fz); }
+            PS_NTT8_EACH(PS_NTT8_STG)
+#undef PS_NTT8_STG
+        }
+    }
+    PS_NTT_STAMP(3);
+#undef PS_NTT8_NORM
+#undef PS_NTT8_EACH
+}
+
+#endif  // PS_NTT_PASS8
+
+#if defined(PS_NTT_TUNE)
+static unsigned long long* g_ntt_trace_buf = nullptr;
+static int g_ntt_launch_no = 0;
+static int g_ntt_trace_meta[6] = {0, 0, 0, 0, 0, 0};  // grid, k, logD, inverse, p, threads of the traced launch
+#endif
 struct NttTables {
     Fr* fwd = nullptr;
     Fr* inv = nullptr;
@@ -263,13 +441,34 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     // a transform that fits one tile runs all its stages in one pass (contiguous in HBM: no stride to respect);
     // longer ones are cut into passes of at most NTT_MAX_K stages (with the 80 KB tile of round 1, measured at 2^20:
     // 8 stages 12.25 ms, 9: 11.9, 10: 11.9; see the note at NTT_TILE_LOG for the tile size)
-    int npass = p <= NTT_TILE_LOG ? 1 : (p + NTT_MAX_K - 1) / NTT_MAX_K;
+    int max_k = NTT_MAX_K, tile_log = NTT_TILE_LOG;
+#if defined(PS_NTT_TUNE)  // measurement builds: pass shapes from the environment (tools/ntt_tune.sh)
+    if (const char* e = getenv("PS_NTT_MAXK")) max_k = atoi(e);
+    if (const char* e = getenv("PS_NTT_TILE")) tile_log = atoi(e);
+#endif
+    int npass = p <= tile_log ? 1 : (p + max_k - 1) / max_k;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
     int done = 0, unscaled = 0;  // unscaled: inverse stages whose factor 2 per stage has not been divided out yet
+    // stages per pass: nearly equal, except that k_ntt_pass8 works in windows of three stages -- passes of six stages behind
+    // a first one of up to nine need the fewest windows (2^21 points: 9 + 6 + 6 = seven windows, 7 + 7 + 7 = nine)
+    int ks[8];
+    {
+        int left = p;
+        for (int i = 0; i < npass; i++) { ks[i] = (left + (npass - i) - 1) / (npass - i); left -= ks[i]; }
+#if defined(PS_NTT_PASS8)
+        const int k0 = p - 6 * (npass - 1);
+        // the long pass is the one that runs on contiguous data (logD = 0: the inverse's first, the forward's last); the strided
+        // passes then keep 16 columns = 640-byte runs
+        if (npass >= 2 && k0 >= 4 && k0 <= max_k && max_k >= 6) {
+            for (int i = 0; i < npass; i++) ks[i] = 6;
+            ks[INV ? 0 : npass - 1] = k0;
+        }
+#endif
+    }
     for (int ps_i = 0; ps_i < npass; ps_i++) {
-        int k = (p - done + (npass - ps_i) - 1) / (npass - ps_i);
+        int k = ks[ps_i];
         int logD = INV ? done : (p - done - k);
-        int logCols = NTT_TILE_LOG - k;
+        int logCols = tile_log - k;
         if (logCols > log_total - k) logCols = log_total - k;
         if (logCols < 0) logCols = 0;
         u64 cols_total = total >> k;
@@ -289,11 +488,67 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         int scale_log = 0;
         if (INV) {
             unscaled += k;
-            const int next_k = ps_i + 1 < npass ? (p - done - k + (npass - ps_i - 1) - 1) / (npass - ps_i - 1) : 0;
+            const int next_k = ps_i + 1 < npass ? ks[ps_i + 1] : 0;
             if (ps_i == npass - 1 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
         }
+#if defined(PS_NTT_PASS8)
+        if (smem > 64 * 1024) {  // tiles beyond the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+            static bool raised = false;
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass8<INV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                raised = true;
+            }
+        }
+        if (k + logCols >= 6) {  // eight elements per thread (tiles of fewer than 64 elements keep the small kernel)
+#if defined(PS_NTT_TUNE)
+            static const int traced8 = getenv("PS_NTT_TRACE_LAUNCH") ? atoi(getenv("PS_NTT_TRACE_LAUNCH")) : -1;
+            const bool trace8 = g_ntt_launch_no++ == traced8 && grid <= 8192;
+            if (trace8) {
+                if (!g_ntt_trace_buf && hipMalloc((void**)&g_ntt_trace_buf, 4 * 8192 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipStreamSynchronize(st);
+                (void)hipMemset(g_ntt_trace_buf, 0, 4 * 8192 * sizeof(unsigned long long));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(ntt_trace), &g_ntt_trace_buf, sizeof(void*));
+                g_ntt_trace_meta[0] = (int)grid; g_ntt_trace_meta[1] = k; g_ntt_trace_meta[2] = logD; g_ntt_trace_meta[3] = INV ? 1 : 0;
+                g_ntt_trace_meta[4] = p; g_ntt_trace_meta[5] = 1 << (k + logCols - 3);
+            }
+#endif
+            hipLaunchKernelGGL(k_ntt_pass8<INV>, dim3(grid), dim3(1u << (k + logCols - 3)), smem, st, data, p, logD, k, logCols,
+                               INV ? tb.inv : tb.fwd, tb.log_tab, fz, scale_log);
+#if defined(PS_NTT_TUNE)
+            if (trace8) {
+                (void)hipStreamSynchronize(st);
+                unsigned long long* none = nullptr;
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(ntt_trace), &none, sizeof(void*));
+            }
+#endif
+            done += k;
+            continue;
+        }
+#endif
+#if defined(PS_NTT_TUNE)
+        // PS_NTT_TRACE_LAUNCH=i: the i-th pass launched by this process leaves its workgroups' phase stamps in a buffer that
+        // ps_debug_ntt_trace copies out (tools/ntt_phases.py)
+        static const int traced = getenv("PS_NTT_TRACE_LAUNCH") ? atoi(getenv("PS_NTT_TRACE_LAUNCH")) : -1;
+        const bool trace_this = g_ntt_launch_no++ == traced && grid <= 8192;
+        if (trace_this) {
+            if (!g_ntt_trace_buf && hipMalloc((void**)&g_ntt_trace_buf, 4 * 8192 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+            (void)hipStreamSynchronize(st);
+            (void)hipMemset(g_ntt_trace_buf, 0, 4 * 8192 * sizeof(unsigned long long));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ntt_trace), &g_ntt_trace_buf, sizeof(void*));
+            g_ntt_trace_meta[0] = (int)grid; g_ntt_trace_meta[1] = k; g_ntt_trace_meta[2] = logD; g_ntt_trace_meta[3] = INV ? 1 : 0;
+            g_ntt_trace_meta[4] = p; g_ntt_trace_meta[5] = (int)threads;
+        }
+#endif
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
                            INV ? tb.inv : tb.fwd, tb.log_tab, fz, scale_log);
+#if defined(PS_NTT_TUNE)
+        if (trace_this) {
+            (void)hipStreamSynchronize(st);
+            unsigned long long* none = nullptr;
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(ntt_trace), &none, sizeof(void*));
+        }
+#endif
         done += k;
     }
     return hipGetLastError();

@@ -1,5 +1,7 @@
 """Differential soak of the MSM against the CPU oracle: random lengths, groups, window sizes (forced, automatic, window
-tables), slice lengths and scalar distributions (uniform, short, skewed, zeros, r - 1, repeated points).
+tables), slice lengths, tail (chains / trees of lane-cooperative additions / automatic), scalar distributions (uniform,
+short, skewed, zeros, r - 1, repeated points); every fourth case a multi-sum over arrays of BOTH groups (one sort, one
+plan) or a burst of sums in flight.
   python3 tools/fuzz_msm.py [seconds] [seed]        (GPU box; exits non-zero on the first mismatch)"""
 import os
 import random
@@ -53,6 +55,8 @@ while time.time() < t_end:
     m = rnd.choice([0, 0, 1, 2, 5, 8, 32, 100])
     if m:
         ctx.set_slice(m)
+    tail = rnd.choice([0, 0, 1, 2, 2])
+    ctx.set_tail(tail)
     try:
         poly = api.Poly.upload(ctx, sc)
         got = poly.BlindEval(pts)
@@ -65,11 +69,33 @@ while time.time() < t_end:
             if got2 != want2:
                 print("MISMATCH (slice)", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, first=f, count=cnt, seed=seed, case=cases))
                 sys.exit(1)
+        if cases % 4 == 3 and n <= 3000:
+            # the same scalars over arrays of both groups in ONE call (PHGR13's shape), or three sums in flight
+            other_name = "G2" if group == "G1" else "G1"
+            oo, ogid = getattr(co, other_name), getattr(api, other_name)
+            raw_o = oo.gen_points(rnd.randrange(1, pr.R), rnd.randrange(1, pr.R), n)
+            pts_o = api.Points.upload(ctx, ogid, raw_o)
+            if mode == "table":
+                pts_o.precompute(c)
+            want_o = oo.to_b(oo.msm_pippenger(co.pack_fr(sc), raw_o, n, 4))
+            if rnd.random() < 0.5:
+                got_m = api.msm_multi(ctx, [pts, pts_o, pts], poly)
+                if got_m != [want, want_o, want]:
+                    print("MISMATCH (multi)", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, tail=tail, seed=seed, case=cases))
+                    sys.exit(1)
+            else:
+                for pp in (pts, pts_o, pts):
+                    api.msm_launch(ctx, pp, poly)
+                got_f = [api.msm_finish(ctx, gg) for gg in (gid, ogid, gid)]
+                if got_f != [want, want_o, want]:
+                    print("MISMATCH (in flight)", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, tail=tail, seed=seed, case=cases))
+                    sys.exit(1)
     finally:
         ctx.set_window(0)
         ctx.set_slice(0)
+        ctx.set_tail(0)
     if got != want:
-        print("MISMATCH", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, seed=seed, case=cases, info=ctx.last_msm_info()))
+        print("MISMATCH", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, tail=tail, seed=seed, case=cases, info=ctx.last_msm_info()))
         sys.exit(1)
     cases += 1
     if cases % 50 == 0:

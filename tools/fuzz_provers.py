@@ -19,9 +19,13 @@ t_end = time.time() + budget
 cases = 0
 while time.time() < t_end:
     n = rnd.choice([2, 3, 4, 5, 8, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 129, rnd.randrange(2, 260)])
+    if cases % 8 == 7:  # keys of >= 1024 points: window tables, the tree tail over a table plan, multi-sums over both groups
+        n = rnd.choice([1024, 1500, 2048, rnd.randrange(1024, 3000)])
     kind = rnd.choice(["synthetic", "synthetic", "bits"])
     c, sol = rs.synthetic_circuit(n, x0=rnd.randrange(2, 1000)) if kind == "synthetic" else rs.bit_circuit(n, seed=rnd.randrange(1 << 30))
     nio = rnd.randrange(1, c.nbVars)  # the reference's diff quirk: the first non-IO index is nbVars - nbIO
+    if n >= 1024 and rnd.random() < 0.7:
+        nio = c.nbVars - rnd.randrange(1, 6)  # most variables on the prover's side, as in a real circuit
     c = rs.SparseR1CS(c.nbVars, nio, c.left, c.right, c.out)
     q = api.QAP(ctx, c.nbVars, c.nbIO, c.left, c.right, c.out)
     dsol = api.Poly.upload(ctx, sol)
@@ -35,6 +39,7 @@ while time.time() < t_end:
     want = rs.groth16_setup(c, *tox)
     tr, vk = api.NewGroth16TrustedSetup(q, *tox)
     r, s = fr(), fr()
+    ctx.set_tail(rnd.choice([0, 0, 1, 2]))
     ref = rs.groth16_prove(want, c, sol, r, s, fast=n > 16)
     for key in (tr, tr.monomial_only()):
         p = api.Groth16Prove(key, q, dsol, r, s)
@@ -64,6 +69,7 @@ while time.time() < t_end:
             if getattr(p, f) != getattr(refp, f):
                 print("MISMATCH phgr13", f, info)
                 sys.exit(1)
+    ctx.set_tail(0)
     cases += 1
     if cases % 10 == 0:
         print(cases, "cases ok", flush=True)
