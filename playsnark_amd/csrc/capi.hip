@@ -998,7 +998,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         st = wc->tail;   // ---- the rest runs on the high-priority tail stream ----
         HIP_TRY(hipStreamWaitEvent(st, wc->ev_acc_local, 0));
     }
-    if (pl.qtail && pl.lpb >= 1) {
+    if (pl.shortsum && pl.lpb >= 1) {
         // the plan of a multi-sum is shared by arrays of both groups (PHGR13: six G1 sums and a G2 one over one sort): the
         // quads of a bucket must fit THIS group's 256-thread block (64 G1 points, 32 G2 points)
         const u32 lpb = std::min<u32>((u32)pl.lpb, 256 / QTraits<KF>::GL);
@@ -1036,19 +1036,41 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
                 u32 np = std::min<u32>(QNP, std::max(rows, cols));
                 while (np > 64 / QGL && (u64)np * QGL * (rows + cols) * (u32)pl.sets > 2048ull * 64) np >>= 1;
                 hipLaunchKernelGGL(k_qreduce_rowcol<KF>, dim3((rows + cols) * (u32)pl.sets), dim3(np * QGL), np * QGL * sizeof(Fp), st,
-                                   (const Xyzz<F>*)wc->buckets.p, cb, s, R, C);
+                                   (const Xyzz<F>*)wc->buckets.p, cb, s, R, C, (const Xyzz<F>*)nullptr, (Xyzz<F>*)nullptr);
             }
             const u32 terms = std::max(rows, cols / 2);
             const u32 np = std::min<u32>(QNP, std::max<u32>(terms, 64 / QGL));
             hipLaunchKernelGGL(k_qreduce_bits<KF>, dim3(nres), dim3(np * QGL), np * QGL * sizeof(Fp), st,
                                s > 0 ? (const Xyzz<F>*)R : (const Xyzz<F>*)wc->buckets.p, (const Xyzz<F>*)C, cb, s, (Xyzz<F>*)wc->wins.p,
-                               (const u32*)c->offs.p + G, (u32*)((Xyzz<F>*)wc->wins.p + (pl.sets > 1 ? nres + (size_t)pl.sets : (size_t)nres)));
+                               (const u32*)c->offs.p + G, (u32*)((Xyzz<F>*)wc->wins.p + (pl.sets > 1 ? nres + (size_t)pl.sets : (size_t)nres)),
+                               (const Xyzz<F>*)nullptr);
         } else if (rp.small) {
             hipLaunchKernelGGL(k_reduce_small<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
                                (const Xyzz<F>*)wc->buckets.p, pl.NB, rp.njobs, (Xyzz<F>*)wc->wins.p);
         } else {
             hipLaunchKernelGGL(k_reduce_l1<KF>, dim3(nblocks((size_t)nseg_total * LN)), dim3(256), 0, st, (const Xyzz<F>*)wc->buckets.p,
                                nseg_total, accs, runs);
+            if (pl.hybrid && rp.segs >= 64) {
+                // Behind the 8-bucket running sums the parallelism is gone (2^16 segments at 2^20 points) and what is left is
+                // depth: sum = sum_s acc_s + 8 sum_s s run_s, the second sum by rows, columns and bits of s on quads (qtail.cuh)
+                // -- the same 4 + kb results [A, W_0, W_1, ..] the pyramid leaves ([A, Q0, Q1, Q2, T_0, ..]), 9 + 8 quad additions
+                // deep instead of 7 + 14 + 6 one-lane ones: 0.45 -> 0.13 ms of a lone 2^20-point sum.
+                constexpr u32 QGL = QTraits<KF>::GL, QNP = 512 / QGL;
+                int cb2 = 0;
+                while ((1u << cb2) < rp.segs) cb2++;
+                const int s2 = (cb2 + 1) / 2;
+                const u32 rows2 = 1u << (cb2 - s2), cols2 = 1u << s2;
+                Xyzz<F>* R_run = lvl;
+                Xyzz<F>* C_run = R_run + (size_t)pl.sets * rows2;
+                Xyzz<F>* R_acc = C_run + (size_t)pl.sets * cols2;
+                u32 np = std::min<u32>(QNP, std::max(rows2, cols2));
+                while (np > 64 / QGL && (u64)np * QGL * (2 * rows2 + cols2) * (u32)pl.sets > 2048ull * 64) np >>= 1;
+                hipLaunchKernelGGL(k_qreduce_rowcol<KF>, dim3((2 * rows2 + cols2) * (u32)pl.sets), dim3(np * QGL), np * QGL * sizeof(Fp), st,
+                                   (const Xyzz<F>*)runs, cb2, s2, R_run, C_run, (const Xyzz<F>*)accs, R_acc);
+                const u32 np2 = std::min<u32>(QNP, std::max<u32>(std::max(rows2, cols2 / 2), 64 / QGL));
+                hipLaunchKernelGGL(k_qreduce_bits<KF>, dim3(nres), dim3(np2 * QGL), np2 * QGL * sizeof(Fp), st, (const Xyzz<F>*)R_run,
+                                   (const Xyzz<F>*)C_run, cb2, s2, (Xyzz<F>*)wc->wins.p, (const u32*)nullptr, (u32*)nullptr, (const Xyzz<F>*)R_acc);
+            } else {
             hipLaunchKernelGGL(k_reduce_pyr<KF>, dim3(nblocks(5 * (size_t)per_role * LN)), dim3(256), 0, st, (const Xyzz<F>*)accs,
                                (const Xyzz<F>*)runs, rp.segs, rp.m, (u32)pl.sets, lvl);
             hipLaunchKernelGGL(k_reduce_sum<KF>, dim3(nres * rp.nblk), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
@@ -1056,6 +1078,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
             if (rp.nblk > 1)
                 hipLaunchKernelGGL(k_reduce_fin<KF>, dim3(nres), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
                                    (const Xyzz<F>*)pieces, rp.nblk, (Xyzz<F>*)wc->wins.p);
+            }
         }
         if (pl.sets > 1)  // per-set weights on the device; the set sums follow the partial results in `wins`
             hipLaunchKernelGGL(k_reduce_weights<KF>, dim3((unsigned)pl.sets), dim3(RED_SUM_LANES * LN), RED_SUM_LANES * sizeof(Xyzz<F>), st,
@@ -1080,9 +1103,10 @@ static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int ma
     // a forced window size means "the plain path with this c" (A/B runs); entries keep 26 bits for the index
     return st->table.load(std::memory_order_acquire) && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
 }
-// Short sums (fewer than PS_QTAIL_MAX_ENTRIES digits): the chip is mostly idle behind the accumulation and the sum's time
-// is the depth of its dependency chain, so the tail runs as trees of lane-cooperative additions (qtail.cuh) and the slices
-// are as short as keeps one wave per SIMD busy.  forced: 0 automatic, 1 the chains of the long sums, 2 the trees.
+// Behind the accumulation the chip is mostly idle and a sum's time is the depth of its dependency chain, so the tail runs as
+// trees of lane-cooperative additions (qtail.cuh) wherever that costs little lane-time.  Short sums (fewer than
+// PS_QTAIL_MAX_ENTRIES digits) also get slices as short as keeps one wave per SIMD busy and a tree fix-up.
+// forced: 0 automatic, 1 the chains of round 2 throughout, 2 the trees wherever they apply.
 #ifndef PS_QTAIL_MAX_ENTRIES
 #define PS_QTAIL_MAX_ENTRIES (1ull << 21)
 #endif
@@ -1098,14 +1122,19 @@ static void msm_plan_lpb(MsmPlan& pl, size_t n, int group) {
 }
 static void msm_plan_tail(MsmPlan& pl, size_t n, int group, int forced, bool busy) {
     const u64 total = (u64)pl.W * n;
-    pl.qtail = forced ? forced == 2 : (total < PS_QTAIL_MAX_ENTRIES && pl.NB <= (1u << 16));
+    // the reduction: quads over the buckets themselves while all sets together hold <= 2^16 buckets (2 quad additions per
+    // bucket: a few per cent of the accumulation's lane-time even with sums in flight); beyond, running sums first
+    pl.qtail = forced ? forced == 2 : pl.G <= (1ull << 16);
+    pl.hybrid = forced != 1;
+    pl.shortsum = forced ? (forced == 2 && total < PS_QTAIL_MAX_ENTRIES) : total < PS_QTAIL_MAX_ENTRIES;
     pl.lpb = 0;
     pl.rc_s = 0;
-    if (!pl.qtail) return;
-    const u32 np = 512 / (group == PS_G1 ? 4 : 8);  // quads of a reduction block
-    const int cb = pl.c - 1;
-    pl.rc_s = (pl.NB / 2 <= 2 * np) ? 0 : (cb + 1) / 2;  // small sets: bit sums straight from the buckets
-    if (!forced || total < PS_QTAIL_MAX_ENTRIES) {
+    if (pl.qtail) {
+        const u32 np = 512 / (group == PS_G1 ? 4 : 8);  // quads of a reduction block
+        const int cb = pl.c - 1;
+        pl.rc_s = (pl.NB / 2 <= 2 * np) ? 0 : (cb + 1) / 2;  // small sets: bit sums straight from the buckets
+    }
+    if (pl.shortsum) {
         // one wave per SIMD when the sum is alone (the shortest chain that still fills the chip); two when other sums are in
         // flight (2^16 points, A/B on one box: slices of 16 / 8 entries 0.504 / 0.519 ms alone, 0.348 / 0.328 in flight)
         const u64 threads = (group == PS_G1 ? (1ull << 16) : (1ull << 15)) << (busy ? 1 : 0);
@@ -1140,7 +1169,7 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
         if (pts[i]->group == PS_G2) plan_group = PS_G2;
     msm_plan_tail(pl, n, plan_group, c->forced_tail, c->q_len > 0);
     if (c->forced_slice) pl.M = c->forced_slice;
-    if (pl.qtail) msm_plan_lpb(pl, n, plan_group);
+    if (pl.shortsum) msm_plan_lpb(pl, n, plan_group);
     if ((u64)pl.W * (u64)n >= (1ull << 32))
         return fail(PS_ERR_ARG, "MSM too long: windows x length = " + std::to_string((u64)pl.W * (u64)n) +
                                     " digits do not fit the 32-bit sort offsets (split the sum, e.g. ps_points_slice)");
@@ -1368,7 +1397,7 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         // below that the host's ~25 launches per sum are the bound)
         const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;
         hipEvent_t wait = (chained && c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
-        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr, pl.qtail && c->q_len == 0);
+        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr, pl.shortsum && c->q_len == 0);
         if (rc) return rc;
         c->last_chain = wc;
         e = {pts->group, pl, wc};

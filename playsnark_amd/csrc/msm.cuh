@@ -36,10 +36,12 @@ struct MsmPlan {
     int SEG;     // buckets per reduction thread
     int sets;    // bucket sets: W, or 1 when the points come with their window table 2^(c w) P (all windows share one set)
     bool table;  // the point pass reads the window table (a plain plan with a single window also has sets == 1)
-    // the tail of a short sum as trees of lane-cooperative additions (qtail.cuh) instead of chains
-    bool qtail;  // k_qfixup / k_qreduce_* instead of k_fixup / k_reduce_*
-    int lpb;     // quads per bucket in k_qfixup (0: the one-thread-per-bucket k_fixup)
-    int rc_s;    // column bits of the row / column split of a bucket set (0: bit sums straight from the buckets)
+    // trees of lane-cooperative additions (qtail.cuh) instead of chains, decided separately for the two halves of the tail:
+    bool qtail;   // REDUCTION by rows / columns / bits of the buckets themselves (k_qreduce_*): bucket sets of <= 2^16 buckets in all
+    bool hybrid;  // ... else the 8-bucket running sums (k_reduce_l1) and quads behind them; false: the chains of round 2 throughout
+    bool shortsum;  // fewer than PS_QTAIL_MAX_ENTRIES digits: short slices, cut buckets summed by quads (k_qfixup), one stream when alone
+    int lpb;      // quads per bucket in k_qfixup (0: the one-thread-per-bucket k_fixup)
+    int rc_s;     // column bits of the row / column split of a bucket set (0: bit sums straight from the buckets)
 };
 // Entries of the sorted list: point index | window << ENTRY_W_SHIFT | sign << 31.  The window field is used only
 // with a window table (then the index must fit ENTRY_W_SHIFT bits); without one the index may use all 31 bits.

@@ -220,25 +220,32 @@ __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u3
 // ---- reduction, first level: row sums R[set][hi] and column sums C[set][lo] of the 2^(cb-s) x 2^s bucket matrix ----
 // One block per row / column; each quad takes every NP-th term, then the tree.
 template <class KF>
+// `extra` (optional): a second array of the same shape whose ROW sums go to R2 (jobs rows + cols .. 2 rows + cols - 1): the
+// long sums' hybrid tail reduces the segments' `run` sums by rows and columns and needs the plain total of their `acc` sums.
 __global__ void __launch_bounds__(512) k_qreduce_rowcol(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets, int cb, int s,
                                                          Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R,
-                                                         Xyzz<typename FieldTraits<KF>::Store>* __restrict__ C) {
+                                                         Xyzz<typename FieldTraits<KF>::Store>* __restrict__ C,
+                                                         const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ extra,
+                                                         Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R2) {
     constexpr u32 GL = QTraits<KF>::GL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fp* sm = reinterpret_cast<Fp*>(smem_raw);
-    const u32 rows = 1u << (cb - s), cols = 1u << s, jobs = rows + cols;
+    const u32 rows = 1u << (cb - s), cols = 1u << s, jobs = rows + cols + (extra ? rows : 0u);
     const u32 set = blockIdx.x / jobs, job = blockIdx.x % jobs;
-    const Xyzz<typename FieldTraits<KF>::Store>* B = buckets + ((size_t)set << cb);
+    const bool second = job >= rows + cols;
+    const Xyzz<typename FieldTraits<KF>::Store>* B = (second ? extra : buckets) + ((size_t)set << cb);
     const u32 pt = threadIdx.x / GL, NP = blockDim.x / GL;
     KF acc = f_zero((const KF*)0);
-    if (job < rows) {
-        for (u32 i = pt; i < cols; i += NP) { const KF p = q_load<KF>(&B[(size_t)job * cols + i]); q_add<KF>(acc, p); }
+    if (job < rows || second) {
+        const u32 row = second ? job - rows - cols : job;
+        for (u32 i = pt; i < cols; i += NP) { const KF p = q_load<KF>(&B[(size_t)row * cols + i]); q_add<KF>(acc, p); }
     } else {
         const u32 lo = job - rows;
         for (u32 i = pt; i < rows; i += NP) { const KF p = q_load<KF>(&B[(size_t)i * cols + lo]); q_add<KF>(acc, p); }
     }
     q_block_tree<KF>(sm, acc, pt, NP);
-    if (pt == 0) q_store<KF>(job < rows ? &R[(size_t)set * rows + job] : &C[(size_t)set * cols + (job - rows)], acc);
+    if (pt == 0)
+        q_store<KF>(second ? &R2[(size_t)set * rows + (job - rows - cols)] : job < rows ? &R[(size_t)set * rows + job] : &C[(size_t)set * cols + (job - rows)], acc);
 }
 
 // ---- reduction, second level: per set cb + 1 results  [S, W_0 .. W_{cb-1}],  set sum = S + sum_k 2^k W_k ----
@@ -250,7 +257,8 @@ template <class KF>
 __global__ void __launch_bounds__(512) k_qreduce_bits(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R,
                                                        const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ C, int cb, int s,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out,
-                                                       const u32* __restrict__ entries_src, u32* __restrict__ entries_dst) {
+                                                       const u32* __restrict__ entries_src, u32* __restrict__ entries_dst,
+                                                       const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R0) {
     constexpr u32 GL = QTraits<KF>::GL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fp* sm = reinterpret_cast<Fp*>(smem_raw);
@@ -259,8 +267,9 @@ __global__ void __launch_bounds__(512) k_qreduce_bits(const Xyzz<typename FieldT
     const u32 pt = threadIdx.x / GL, NP = blockDim.x / GL;
     if (blockIdx.x == 0 && threadIdx.x == 0 && entries_dst) *entries_dst = *entries_src;  // the entry count rides along
     KF acc = f_zero((const KF*)0);
-    if (job == 0) {
-        for (u32 i = pt; i < rows; i += NP) { const KF p = q_load<KF>(&R[(size_t)set * rows + i]); q_add<KF>(acc, p); }
+    if (job == 0) {  // R0 (optional): the row sums whose total is job 0's result instead of R's (k_qreduce_rowcol's `extra`)
+        const Xyzz<typename FieldTraits<KF>::Store>* src0 = (R0 ? R0 : R) + (size_t)set * rows;
+        for (u32 i = pt; i < rows; i += NP) { const KF p = q_load<KF>(&src0[i]); q_add<KF>(acc, p); }
     } else {
         const u32 k = job - 1;
         const bool fromC = k < (u32)s;
