@@ -79,7 +79,7 @@ struct ps_ctx {
     // high-priority stream: when it shares the chip with another sum's accumulation, its few
     // workgroups are dispatched ahead of the thousands the accumulation has queued.
     hipStream_t tail = nullptr;
-    hipEvent_t ev_acc_local = nullptr, ev_tail_done = nullptr;
+    hipEvent_t ev_acc_local = nullptr, ev_tail_done = nullptr, ev_sort_local = nullptr;
     bool tail_used = false;
     // MSM workspace
     DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts, coarse;
@@ -221,6 +221,7 @@ extern "C" int ps_ctx_create(int device, ps_ctx** out) {
         HIP_TRY(hipStreamCreateWithPriority(&c->tail, hipStreamNonBlocking, greatest));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_acc_local, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&c->ev_tail_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_sort_local, hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc((void**)&c->d_flag, 64));
     c->h_pinned_cap = PS_MSM_MULTI_MAX * PS_PINNED_SLOT + 64;
@@ -259,6 +260,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_acc_local) (void)hipEventDestroy(c->ev_acc_local);
     if (c->ev_tail_done) (void)hipEventDestroy(c->ev_tail_done);
+    if (c->ev_sort_local) (void)hipEventDestroy(c->ev_sort_local);
     if (c->tail) (void)hipStreamDestroy(c->tail);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -858,7 +860,11 @@ extern "C" int ps_points_sum(int group, const uint8_t* pts, size_t k, uint8_t* o
 // point pass (accumulate, fixup, reduce) on one point array.  ps_msm_multi runs one sort for several
 // point arrays that share a scalar vector (computeSolCommit x9, pinochio.go:231-241).
 #define PS_STAGE_MARK() do { if (timed) HIP_TRY(hipEventRecord(c->ev[evi++], st)); } while (0)
-static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool timed) {
+// `st`: the stream the sort runs on.  With sums in flight that is the workspace's HIGH-PRIORITY stream: the sort of sum i+1
+// shares the chip with the accumulation of sum i, whose waves hold 468 of a SIMD's 512 registers -- on the normal-priority
+// stream its workgroups were dispatched behind the accumulation's own (k_sort_partition: 2.0-2.6 ms instead of 0.09 in a
+// kernel trace of 2^20-point sums), the next accumulation waited for it, and the step was 2.78 ms for 2.30 ms of accumulation.
+static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool timed, hipStream_t st) {
     const size_t n = sc->n;
     const u64 total = (u64)pl.W * n;  // upper bound on entries
     const u64 G = pl.G;
@@ -871,7 +877,6 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     if ((rc = c->ranks.ensure(4 * total))) return rc;
     if ((rc = c->vals.ensure(4 * total))) return rc;
     if ((rc = c->sorted.ensure(4 * total + 4))) return rc;
-    hipStream_t st = c->stream;
     if (c->tail_used) HIP_TRY(hipStreamWaitEvent(st, c->ev_tail_done, 0));  // the last tail still reads offs
     if (storage_wait_ready(sc->st, st)) return fail(PS_ERR_HIP, "msm: event wait failed");  // asynchronously produced scalars
     int evi = 0;
@@ -1055,7 +1060,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
                 // depth: sum = sum_s acc_s + 8 sum_s s run_s, the second sum by rows, columns and bits of s on quads (qtail.cuh)
                 // -- the same 4 + kb results [A, W_0, W_1, ..] the pyramid leaves ([A, Q0, Q1, Q2, T_0, ..]), 9 + 8 quad additions
                 // deep instead of 7 + 14 + 6 one-lane ones: 0.45 -> 0.13 ms of a lone 2^20-point sum.
-                constexpr u32 QGL = QTraits<KF>::GL, QNP = 512 / QGL;
+                constexpr u32 QGL = QTraits<KF>::GL, QNP = 256 / QGL;  // 256-thread blocks: one fits where ONE accumulation block retired
                 int cb2 = 0;
                 while ((1u << cb2) < rp.segs) cb2++;
                 const int s2 = (cb2 + 1) / 2;
@@ -1182,8 +1187,13 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
 #endif
 static int msm_launch_any(ps_ctx* wc, const ps_points* pts, const ps_scalars* sc, const MsmPlan& pl, hipEvent_t wait_acc,
                           hipEvent_t acc_done, bool inline_tail) {
-    int rc = msm_sort(wc, sc, pl, wc->timing);
+    hipStream_t ss = inline_tail ? wc->stream : wc->tail;  // a lone short sum keeps one stream
+    int rc = msm_sort(wc, sc, pl, wc->timing, ss);
     if (rc) return rc;
+    if (ss != wc->stream) {
+        HIP_TRY(hipEventRecord(wc->ev_sort_local, ss));
+        HIP_TRY(hipStreamWaitEvent(wc->stream, wc->ev_sort_local, 0));
+    }
     rc = pts->group == PS_G1 ? msm_points_t<Fp>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done, inline_tail)
                              : msm_points_t<Fp2>(wc, wc, pts, sc->n, pl, wc->timing, 0, wait_acc, acc_done, inline_tail);
     wc->ev_valid = wc->timing && !rc;
@@ -1247,16 +1257,16 @@ constexpr int PS_MULTI_RING = 4;
 static int msm_multi_sort(ps_ctx* c, ps_ctx* const* ring, const ps_scalars* sc, const MsmPlan& pl, bool fork) {
     int rc;
     ps_ctx* w0 = ring[0];
-    if (w0 != c && fork) {  // inputs prepared on the context stream are visible to the worker streams
+    if (fork) {  // inputs prepared on the context stream are visible to the stream the sort runs on
         if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(hipStreamWaitEvent(w0->stream, c->ev_fork, 0));
+        HIP_TRY(hipStreamWaitEvent(w0->tail, c->ev_fork, 0));
     }
-    if ((rc = msm_sort(w0, sc, pl, false))) return rc;
+    if ((rc = msm_sort(w0, sc, pl, false, w0->tail))) return rc;  // high priority: see msm_sort
     w0->ev_valid = false;
     if (!c->ev_sorted) HIP_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(c->ev_sorted, w0->stream));
-    for (int j = 1; j < PS_MULTI_RING; j++) {
+    HIP_TRY(hipEventRecord(c->ev_sorted, w0->tail));
+    for (int j = 0; j < PS_MULTI_RING; j++) {
         bool seen = false;
         for (int i = 0; i < j; i++) seen = seen || ring[i] == ring[j];
         if (!seen) HIP_TRY(hipStreamWaitEvent(ring[j]->stream, c->ev_sorted, 0));
@@ -1391,13 +1401,15 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         int rc0 = msm_plan_checked(c, &pts, 1, sc->n, sc->max_bits, &pl);
         if (rc0) return rc0;
         if (wc != c) HIP_TRY(hipStreamWaitEvent(wc->stream, c->ev_fork, 0));
+        const bool lone = pl.shortsum && c->q_len == 0;
+        if (!lone) HIP_TRY(hipStreamWaitEvent(wc->tail, c->ev_fork, 0));  // the sort runs on the workspace's high-priority stream
         // chain the accumulations: this one starts when the previously launched one is done
         // ... unless the sum is short: accumulations of a few hundred thousand entries do not fill the chip, and chained
         // they are three launch latencies in a row (A/B on one box: Groth16 on 2^10 constraints 1.62 -> 1.54 ms, PHGR13 on 2^14 4.25 -> 3.9 ms;
         // below that the host's ~25 launches per sum are the bound)
         const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;
         hipEvent_t wait = (chained && c->last_chain && c->last_chain != wc) ? c->last_chain->ev_acc_local : nullptr;
-        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr, pl.shortsum && c->q_len == 0);
+        int rc = msm_launch_any(wc, pts, sc, pl, wait, nullptr, lone);
         if (rc) return rc;
         c->last_chain = wc;
         e = {pts->group, pl, wc};

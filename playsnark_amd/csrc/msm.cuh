@@ -500,7 +500,8 @@ __global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __rest
     if (tid == 0) tile_base[ncoarse] = ttotal;
 }
 
-__global__ void __launch_bounds__(DIGITS_THREADS) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set, int fb,
+// (16 waves of at most 64 registers: the block fits beside ONE wave per SIMD of another sum's accumulation, 240 + 256 <= 512)
+__global__ void __launch_bounds__(DIGITS_THREADS, 8) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set, int fb,
                                                                    u32* __restrict__ coarse_cur, unsigned short* __restrict__ part_key,
                                                                    u32* __restrict__ part_val) {
     __shared__ u32 hist[SORT_MAX_COARSE], binstart[SORT_MAX_COARSE], gbase[SORT_MAX_COARSE];
@@ -890,8 +891,17 @@ __global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char
 // ---------------------------------------------------------------------------------------
 constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to the heavy-bucket kernels
 
+// Waves per SIMD the tail kernels are compiled for.  2 = at most 256 registers per wave.  With "1" the compiler took 306
+// (k_reduce_l1<Fp>: 256 VGPRs + 50 AGPRs) and 357 (G2): such a wave cannot share a SIMD's 512 registers with ONE wave of
+// another sum's accumulation (234 / 256), so with sums in flight the running sums waited for the accumulation to drain --
+// 2.4 ms instead of 0.26 in a kernel trace of 2^20-point sums three in flight -- and the pipeline stalled behind them
+// (2.78 ms per sum for 2.30 ms of accumulation).
+#ifndef PS_TAIL_WAVES
+#define PS_TAIL_WAVES 2
+#endif
+
 template <class KF>
-__global__ void __launch_bounds__(256, 1) k_fixup(const u32* __restrict__ offs, u32 G, int M,
+__global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restrict__ offs, u32 G, int M,
                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
@@ -1076,7 +1086,7 @@ static inline ReducePlan reduce_plan(u32 NB) {
 }
 
 template <class KF>
-__global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+__global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                       u32 nseg_total, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs) {
     u32 idx = logical_tid<KF>();
@@ -1103,7 +1113,7 @@ __global__ void __launch_bounds__(256, 1) k_reduce_l1(const Xyzz<typename FieldT
 // lvl: five arrays of sets * m points (A1, Q0, Q1, Q2, R1).  Logical thread = (role, set, j); the roles are laid out
 // one after the other so that a wave runs one role.
 template <class KF>
-__global__ void __launch_bounds__(256, 1) k_reduce_pyr(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
+__global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_reduce_pyr(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                        const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs,
                                                        u32 segs, u32 m, u32 sets,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ lvl) {
