@@ -147,7 +147,9 @@ int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, siz
  * (launch i+2, then finish i) hides each sum's sort and its latency-bound tail -- bucket fix-up,
  * reduction, host fold -- under its neighbours' accumulations.  The one-call forms (ps_msm, ps_msm_be32,
  * ps_msm_i64, ps_msm_multi, the provers) need an empty queue (PS_ERR_ARG otherwise). */
+#ifndef PS_MSM_QUEUE
 #define PS_MSM_QUEUE 3
+#endif
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);
 /* k sums over ONE scalar vector: out[i] = sum_j scalars[j] * points[i][j].  The digit sort runs once and

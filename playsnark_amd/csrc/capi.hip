@@ -1040,6 +1040,9 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
                 // 2048 on the chip -- a second round of blocks would double the kernel's time), at most one term per quad
                 u32 np = std::min<u32>(QNP, std::max(rows, cols));
                 while (np > 64 / QGL && (u64)np * QGL * (rows + cols) * (u32)pl.sets > 2048ull * 64) np >>= 1;
+#if defined(PS_TAIL_TUNE)
+                if (pl.busy) if (const char* e = getenv("PS_T_NP_BUSY")) np = std::max<u32>(64 / QGL, std::min<u32>(np, (u32)atoi(e)));
+#endif
                 hipLaunchKernelGGL(k_qreduce_rowcol<KF>, dim3((rows + cols) * (u32)pl.sets), dim3(np * QGL), np * QGL * sizeof(Fp), st,
                                    (const Xyzz<F>*)wc->buckets.p, cb, s, R, C, (const Xyzz<F>*)nullptr, (Xyzz<F>*)nullptr);
             }
@@ -1121,6 +1124,9 @@ static void msm_plan_lpb(MsmPlan& pl, size_t n, int group) {
     const u64 total = (u64)pl.W * n;
     const u64 span = total / (pl.G * (u64)pl.M) + 1;  // slices an average bucket touches, rounded up
     if (pl.G * (u64)gl > (1ull << 17)) { pl.lpb = 0; return; }  // too many buckets for a quad each: one thread per bucket (k_fixup)
+#if defined(PS_TAIL_TUNE)
+    if (pl.busy) if (const char* e = getenv("PS_T_LPB_BUSY")) if (atoi(e) == 0 && pl.G >= 4096) { pl.lpb = 0; return; }
+#endif
     u32 lpb = 1;
     while (lpb < span && lpb * 2 * gl <= 256 && pl.G * (u64)(lpb * 2) * gl <= (1ull << 17)) lpb *= 2;  // one round of blocks (2048 waves)
     pl.lpb = (int)lpb;
@@ -1134,6 +1140,7 @@ static void msm_plan_tail(MsmPlan& pl, size_t n, int group, int forced, bool bus
     pl.shortsum = forced ? (forced == 2 && total < PS_QTAIL_MAX_ENTRIES) : total < PS_QTAIL_MAX_ENTRIES;
     pl.lpb = 0;
     pl.rc_s = 0;
+    pl.busy = busy;
     if (pl.qtail) {
         const u32 np = 512 / (group == PS_G1 ? 4 : 8);  // quads of a reduction block
         const int cb = pl.c - 1;
@@ -1142,7 +1149,10 @@ static void msm_plan_tail(MsmPlan& pl, size_t n, int group, int forced, bool bus
     if (pl.shortsum) {
         // one wave per SIMD when the sum is alone (the shortest chain that still fills the chip); two when other sums are in
         // flight (2^16 points, A/B on one box: slices of 16 / 8 entries 0.504 / 0.519 ms alone, 0.348 / 0.328 in flight)
-        const u64 threads = (group == PS_G1 ? (1ull << 16) : (1ull << 15)) << (busy ? 1 : 0);
+        u64 threads = (group == PS_G1 ? (1ull << 16) : (1ull << 15)) << (busy ? 1 : 0);
+#if defined(PS_TAIL_TUNE)
+        if (busy) if (const char* e = getenv("PS_T_MSHIFT")) threads = (group == PS_G1 ? (1ull << 16) : (1ull << 15)) << atoi(e);
+#endif
         int M = 2;
         while (M < 32 && total / (u64)M > threads) M *= 2;
         pl.M = M;
@@ -1367,7 +1377,7 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
     // a workspace no pending sum is using: the context itself first
     ps_ctx** slots[4] = {nullptr, &c->pipe, &c->pipe2, &c->aux};
     ps_ctx* wc = nullptr;
-    for (int w = allow_self ? 0 : 1; w < (allow_self ? 3 : 4) && !wc; w++) {
+    for (int w = allow_self ? 0 : 1; w < (allow_self ? PS_MSM_QUEUE : 4) && !wc; w++) {
         ps_ctx* cand = w == 0 ? c : *slots[w];
         bool busy = false;
         for (int j = 0; j < c->q_len; j++) busy = busy || (cand && c->q[(c->q_head + j) % PS_MSM_QUEUE].wc == cand);
@@ -1379,6 +1389,7 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
         }
         wc = cand;
     }
+    if (!wc) return fail(PS_ERR_ARG, "ps_msm_launch: no free workspace");
     if (wc != c) {
         wc->timing = c->timing;
         wc->forced_c = c->forced_c;

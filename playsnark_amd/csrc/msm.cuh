@@ -42,6 +42,7 @@ struct MsmPlan {
     bool shortsum;  // fewer than PS_QTAIL_MAX_ENTRIES digits: short slices, cut buckets summed by quads (k_qfixup), one stream when alone
     int lpb;      // quads per bucket in k_qfixup (0: the one-thread-per-bucket k_fixup)
     int rc_s;     // column bits of the row / column split of a bucket set (0: bit sums straight from the buckets)
+    bool busy;    // planned while other sums were pending on the context: lane-time counts, not depth (capi.hip, msm_plan_tail)
 };
 // Entries of the sorted list: point index | window << ENTRY_W_SHIFT | sign << 31.  The window field is used only
 // with a window table (then the index must fit ENTRY_W_SHIFT bits); without one the index may use all 31 bits.

@@ -102,6 +102,15 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr, log2n):
     assert (mono.A, mono.B, mono.C) == (proof.A, proof.B, proof.C)
     del mono_key
     progress("Groth16 proof")
+    # BASELINE config #4 / #5's other half at full size: the shares of 8 ranks (index ranges of Xi, Xi2, NioLP, XiT through
+    # ps_groth16_prove_shard, one after the other on this GPU), folded, are the unsharded proof byte for byte
+    from playsnark_amd.dist import ShardedGroth16, ShardedPHGR13
+    t0 = time.time()
+    sh = ShardedGroth16(ctx, None, 8, 0)
+    folded = sh.fold([sh.partials(tr, q, dsol, r, s, rank=g) for g in range(8)], r, s)
+    t["groth16_8_shares_one_gpu_s"] = time.time() - t0
+    assert (folded.A, folded.B, folded.C) == (proof.A, proof.B, proof.C)
+    progress("Groth16 proof from the shares of 8 ranks")
 
     # ---- TestGroth16ProofGen at full size ----
     t0 = time.time()
@@ -161,6 +170,13 @@ def test_groth16_and_phgr13_at_scale(ps_api, ctx, co, pr, log2n):
         assert getattr(pp, f) == getattr(mono_pp, f), f
     t["phgr13_phase_ms"] = {k: round(v, 2) for k, v in ctx.last_prove_phase_ms().items()}
     progress("PHGR13 setup and proof")
+    t0 = time.time()
+    shp = ShardedPHGR13(ctx, None, 8, 0)
+    folded_pp = shp.fold([shp.partials(ek, q, dsol, rank=g) for g in range(8)])
+    t["phgr13_8_shares_one_gpu_s"] = time.time() - t0
+    for f in ps_api.PHGR13Proof.FIELDS:
+        assert getattr(folded_pp, f) == getattr(pp, f), f
+    progress("PHGR13 proof from the shares of 8 ranks")
     us, vs_, ws_, zs = rs.var_poly_evals(c, sp)
     ry = rv * rw % R
     dot = lambda ev: sum(e * si for e, si in zip(ev[diff:], sol[diff:])) % R
