@@ -88,7 +88,7 @@ int ps_points_upload(ps_ctx* ctx, int group /*PS_G1|PS_G2*/, const uint8_t* pts,
 int ps_points_precompute(ps_ctx* ctx, ps_points* p, int window_bits);
 int ps_points_table_window(const ps_points* p); /* window bits of the table, 0 = none */
 /* ps_groth16_prove / ps_phgr13_prove build the tables of their CRS arrays themselves on first use (keys of at least
- * 1024 points; cached per key; about 9 GB for a 2^20-constraint Groth16 key, 15 GB for a PHGR13 one).
+ * 32 points; cached per key; about 9 GB for a 2^20-constraint Groth16 key, 15 GB for a PHGR13 one).
  * enable = 0 keeps the provers on the plain plan. */
 int ps_ctx_set_tables(ps_ctx* ctx, int enable);
 /* Memory policy of those tables.  A prover builds a table only when it fits: `bytes` >= 0 caps ONE table (0: none fit),

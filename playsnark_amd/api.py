@@ -74,7 +74,7 @@ class Context:
         _check(lib.ps_msm_set_window(self._h, bits))
 
     def set_tables(self, enable: bool):
-        """Whether the provers build window tables for their CRS arrays (default: yes, for keys of >= 1024 points)."""
+        """Whether the provers build window tables for their CRS arrays (default: yes, for keys of >= 32 points)."""
         _check(lib.ps_ctx_set_tables(self._h, int(enable)))
 
     def microbench_mad(self) -> float:

@@ -980,10 +980,15 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
     if ((rc = wc->segs.ensure(sizeof(Xyzz<F>) * (2 * (size_t)nseg_total + 5 * (size_t)per_role + (size_t)nres * rp.nblk)))) return rc;
     if ((rc = wc->wins.ensure(sizeof(Xyzz<F>) * ((size_t)nres + (size_t)pl.sets) + 16))) return rc;
-    const size_t max_heavy = (size_t)(total / ((u64)HEAVY_SPAN * (u64)pl.M)) + 2;  // a heavy bucket holds > SPAN*M entries
+    // a heavy bucket spans >= HEAVY_SPAN slices for the one-lane fix-up, >= QFIX_HEAVY x (quads per bucket) for the quad fix-up
+    const bool qfix = pl.shortsum && pl.lpb >= 1;
+    const u32 qlpb = qfix ? std::min<u32>((u32)pl.lpb, 256 / QTraits<KF>::GL) : 0;
+    const u64 heavy_slices = qfix ? std::min<u64>(HEAVY_SPAN, (u64)QFIX_HEAVY * qlpb - 1) : HEAVY_SPAN;
+    const size_t max_heavy = (size_t)(total / (heavy_slices * (u64)pl.M)) + 2;
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
-    const size_t max_jobs = (size_t)nthreads_acc / HEAVY_CHUNK + max_heavy + 1;
+    const u32 heavy_chunk = qfix ? 256 / QTraits<KF>::GL : HEAVY_CHUNK;  // slices per job
+    const size_t max_jobs = (size_t)nthreads_acc / heavy_chunk + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
     if (sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) + 16 > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
@@ -1006,7 +1011,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     if (pl.shortsum && pl.lpb >= 1) {
         // the plan of a multi-sum is shared by arrays of both groups (PHGR13: six G1 sums and a G2 one over one sort): the
         // quads of a bucket must fit THIS group's 256-thread block (64 G1 points, 32 G2 points)
-        const u32 lpb = std::min<u32>((u32)pl.lpb, 256 / QTraits<KF>::GL);
+        const u32 lpb = qlpb;
         hipLaunchKernelGGL(k_qfixup<KF>, dim3(nblocks(G * (u64)lpb * QTraits<KF>::GL)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
                            lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     } else
@@ -1016,11 +1021,18 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         const u32* hcount = (const u32*)wc->heavy.p;
         const u32* hlist = hcount + 1;
         u32* job_base = (u32*)wc->heavy.p + 1 + max_heavy;
-        hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, hcount, hlist, job_base);
+        hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, hcount, hlist, job_base, heavy_chunk);
+        if (qfix) {  // short sums: two levels of quad trees (qtail.cuh)
+            hipLaunchKernelGGL(k_qfixup_heavy_part<KF>, dim3(1024), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, (const Xyzz<F>*)wc->parts.p,
+                               hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
+            hipLaunchKernelGGL(k_qfixup_heavy<KF>, dim3(256), dim3(256), 0, st, (const Xyzz<F>*)wc->hparts.p, (Xyzz<F>*)wc->buckets.p, hcount,
+                               hlist, (const u32*)job_base);
+        } else {
         hipLaunchKernelGGL(k_fixup_heavy_part<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
                            (const Xyzz<F>*)wc->parts.p, hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
         hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)wc->hparts.p,
                            (Xyzz<F>*)wc->buckets.p, hcount, hlist, (const u32*)job_base);
+        }
     }
     PS_STAGE_MARK();  // 6: after fixup
     {

@@ -939,7 +939,7 @@ constexpr u32 HEAVY_CHUNK = 1024;
 
 // job_base[h] = number of jobs of the heavy buckets before h; job_base[nheavy] = total.  One workgroup.
 __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs, int M, const u32* __restrict__ heavy_count,
-                                                    const u32* __restrict__ heavy_list, u32* __restrict__ job_base) {
+                                                    const u32* __restrict__ heavy_list, u32* __restrict__ job_base, u32 chunk) {
     __shared__ u32 wsum[4];
     const u32 nheavy = *heavy_count;
     const u32 tid = threadIdx.x;
@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs
         if (h < nheavy) {
             const u32 g = heavy_list[h];
             const u32 t0 = offs[g] / (u32)M, t1 = (offs[g + 1] - 1) / (u32)M;
-            cnt = (t1 - t0 + HEAVY_CHUNK) / HEAVY_CHUNK;  // ceil((t1 - t0 + 1) / CHUNK)
+            cnt = (t1 - t0 + chunk) / chunk;  // ceil((t1 - t0 + 1) / chunk)
         }
         u32 inc = wave_incl_scan(cnt);
         if ((tid & 63) == 63) wsum[tid >> 6] = inc;

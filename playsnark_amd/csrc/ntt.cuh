@@ -73,6 +73,7 @@ struct NttFuse {
     const Fr* ld_aux = nullptr;   // SCALE_PAD: the per-element factors
     int st = NTT_ST_PLAIN;
     const Fr* st_aux = nullptr;   // MUL: the per-element factors
+    u64 aux_mask = ~0ull;         // MUL: factor index = element index & aux_mask (a batch of transforms sharing one factor array)
     Fr* st_dst = nullptr;         // COMBINE / TAKE: the array written instead of `data`
     int logs = 0;                 // UPPER_HALF / COMBINE: node size
     u64 cnt = 0;                  // *_PAD / *TAKE: element count
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         if (fz.st == NTT_ST_PLAIN) {
             data[addr] = v;
         } else if (fz.st == NTT_ST_MUL) {
-            data[addr] = fr_mul(v, fz.st_aux[addr]);
+            data[addr] = fr_mul(v, fz.st_aux[addr & fz.aux_mask]);
         } else if (fz.st == NTT_ST_COMBINE) {
             const u64 half = 1ull << (fz.logs - 1);
             fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
@@ -269,7 +270,7 @@ PS_INL void ntt_st(Fr* __restrict__ data, u64 addr, const Fr& v, const NttFuse& 
     if (fz.st == NTT_ST_PLAIN) {
         data[addr] = v;
     } else if (fz.st == NTT_ST_MUL) {
-        data[addr] = fr_mul(v, fz.st_aux[addr]);
+        data[addr] = fr_mul(v, fz.st_aux[addr & fz.aux_mask]);
     } else if (fz.st == NTT_ST_COMBINE) {
         const u64 half = 1ull << (fz.logs - 1);
         fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
@@ -479,7 +480,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         unsigned threads = (unsigned)std::min<u64>(512, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 2));
         NttFuse fz;  // the load belongs to the first pass, the store to the last
         if (ps_i == 0) { fz.ld = fuse.ld; fz.ld_src = fuse.ld_src; fz.ld_aux = fuse.ld_aux; }
-        if (ps_i == npass - 1) { fz.st = fuse.st; fz.st_aux = fuse.st_aux; fz.st_dst = fuse.st_dst; }
+        if (ps_i == npass - 1) { fz.st = fuse.st; fz.st_aux = fuse.st_aux; fz.st_dst = fuse.st_dst; fz.aux_mask = fuse.aux_mask; }
         fz.logs = fuse.logs;
         fz.cnt = fuse.cnt;
         fz.top = fuse.top;

@@ -178,7 +178,7 @@ __device__ inline void q_block_tree(Fp* sm, KF& mine, u32 pt, u32 grp) {
 // ---- fix-up of the buckets cut by slice boundaries: LPB quads per bucket ----
 // Quad `sub` of bucket g sums the partial slots of the slices t0 + sub, t0 + sub + LPB, ..; a tree over the LPB quads
 // follows.  Buckets that span more than QFIX_HEAVY x LPB slices go to the heavy-bucket kernels (msm.cuh section 5).
-constexpr u32 QFIX_HEAVY = 16;
+constexpr u32 QFIX_HEAVY = 16;  // (4: buckets a little above the average went heavy by the thousand -- Groth16 on 2^14 constraints 1.7 -> 2.1 ms)
 template <class KF>
 __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u32 G, int M, u32 LPB,
                                                 const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
@@ -215,6 +215,71 @@ __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u3
     }
     q_block_tree<KF>(sm, acc, pt, LPB);
     if (store && sub == 0) q_store<KF>(&buckets[g], acc);
+}
+
+// ---- heavy buckets of a short sum (a witness that is half ones puts n/2 digits into one bucket; slices are 2..32 entries) ----
+// Two levels of quad trees: jobs of one block's worth of slices (64 G1 / 32 G2 partial sums, one per quad, a tree as deep as
+// the job is long), then per bucket a tree over its jobs' results.  512 partial sums of a G2 bucket (Groth16's B on 2^12
+// constraints of the tiled toy circuit): 5 + 4 quad additions deep, 0.10 ms, where the one-lane kernels of the long sums
+// (k_fixup_heavy_part: strided chains, then a 7-level tree of 20 us lane-pair additions) took 0.31 ms.
+template <class KF>
+__device__ inline u32 q_tree_size(u32 count) {  // the power of two >= count, at most the block's quads
+    constexpr u32 NPB = 256 / QTraits<KF>::GL;
+    u32 g = 1;
+    while (g < count && g < NPB) g <<= 1;
+    return g;
+}
+template <class KF>
+__global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict__ offs, int M,
+                                                            const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
+                                                            const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
+                                                            const u32* __restrict__ job_base,
+                                                            Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts) {
+    constexpr u32 GL = QTraits<KF>::GL, NPB = 256 / GL;
+    __shared__ Fp sm[256];
+    const u32 nheavy = *heavy_count;
+    if (nheavy == 0) return;
+    const u32 njobs = job_base[nheavy];
+    const u32 pt = threadIdx.x / GL;
+    for (u32 j = blockIdx.x; j < njobs; j += gridDim.x) {
+        u32 lo_h = 0, hi_h = nheavy;  // job_base[lo_h] <= j < job_base[hi_h]
+        while (hi_h - lo_h > 1) {
+            const u32 mid = (lo_h + hi_h) >> 1;
+            if (job_base[mid] <= j) lo_h = mid; else hi_h = mid;
+        }
+        const u32 g = heavy_list[lo_h];
+        const u32 lo = offs[g], hi = offs[g + 1];
+        const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
+        const u32 ts = t0 + (j - job_base[lo_h]) * NPB;  // jobs of NPB slices (k_heavy_jobs with chunk = NPB)
+        const u32 te = (t1 - ts >= NPB) ? ts + NPB - 1 : t1;
+        KF acc = f_zero((const KF*)0);
+        if (ts + pt <= te) {
+            const u32 t = ts + pt, slice_start = t * (u32)M;
+            const u32 rs = lo > slice_start ? lo : slice_start;
+            acc = q_load<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
+        }
+        q_block_tree<KF>(sm, acc, pt, q_tree_size<KF>(te - ts + 1));
+        if (pt == 0) q_store<KF>(&hparts[j], acc);
+        __syncthreads();
+    }
+}
+template <class KF>
+__global__ void __launch_bounds__(256) k_qfixup_heavy(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts,
+                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
+                                                       const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
+                                                       const u32* __restrict__ job_base) {
+    constexpr u32 GL = QTraits<KF>::GL, NPB = 256 / GL;
+    __shared__ Fp sm[256];
+    const u32 nheavy = *heavy_count;
+    const u32 pt = threadIdx.x / GL;
+    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const u32 j0 = job_base[h], j1 = job_base[h + 1];
+        KF acc = f_zero((const KF*)0);
+        for (u32 j = j0 + pt; j < j1; j += NPB) { const KF p = q_load<KF>(&hparts[j]); q_add<KF>(acc, p); }
+        q_block_tree<KF>(sm, acc, pt, q_tree_size<KF>(j1 - j0));
+        if (pt == 0) q_store<KF>(&buckets[heavy_list[h]], acc);
+        __syncthreads();
+    }
 }
 
 // ---- reduction, first level: row sums R[set][hi] and column sums C[set][lo] of the 2^(cb-s) x 2^s bucket matrix ----

@@ -242,6 +242,18 @@ __global__ void __launch_bounds__(256) k_lagrange_weights(Fr* __restrict__ out, 
     Fr w = fr_mul(fr_mul(y[j], invfact[j]), invfact[n - 1 - j]);
     out[j] = ((n - 1 - j) & 1) ? fr_neg(w) : w;
 }
+// the same for A, B, C at once: out = [w^A | w^B | w^C | 0], each part L = 2^logL long (a batch of four transforms)
+struct FrPtr3 { const Fr* p[3]; };
+__global__ void __launch_bounds__(256) k_lagrange_weights3(Fr* __restrict__ out, FrPtr3 ys, const Fr* __restrict__ invfact, u64 n, int logL) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (4ull << logL)) return;
+    const u64 j = idx & ((1ull << logL) - 1);
+    const u32 k = (u32)(idx >> logL);
+    if (k == 3 || j >= n) { out[idx] = fr_zero(); return; }
+    const Fr* y = k == 0 ? ys.p[0] : k == 1 ? ys.p[1] : ys.p[2];
+    Fr w = fr_mul(fr_mul(y[j], invfact[j]), invfact[n - 1 - j]);
+    out[idx] = ((n - 1 - j) & 1) ? fr_neg(w) : w;
+}
 // out[d-1] = 1/d = (d-1)! / d!  for d = 1..cnt, 0 up to `total`
 __global__ void __launch_bounds__(256) k_reciprocals(Fr* __restrict__ out, const Fr* __restrict__ fact,
                                                      const Fr* __restrict__ invfact, u64 cnt, u64 total) {
@@ -332,6 +344,7 @@ struct QapTables {
     std::vector<Fr*> zhat_h;     // subproduct tree over the nodes n+1 .. n+np_h
     // work buffers
     Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
+    Fr* s4 = nullptr;            // 8np, short transforms only: the three convolutions of the h-values path as ONE batch
     std::vector<void*> owned;
     void free_all() {
         for (void* p : owned) (void)hipFree(p);
@@ -340,6 +353,9 @@ struct QapTables {
     }
 };
 
+#ifndef QT_BATCH_MAX_L
+#define QT_BATCH_MAX_L (1ull << 16)  // transforms up to this length leave most of the chip idle: the h-values path batches its three
+#endif
 #define QT_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
 static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
@@ -406,6 +422,19 @@ static inline hipError_t quotient_h_values(const NttTables& tabs, hipStream_t st
     if (n < 2) return hipSuccess;
     const Fr* ys[3] = {yA, yB, yC};
     Fr* S[3] = {qt.t1, qt.pa, qt.pb};
+    if (qt.s4) {
+        // Short transforms are latency: a 2^11-point transform is two workgroups walking eleven butterfly stages, ~40 us for
+        // the forward and inverse pair whatever the chip could do beside it (kernel trace of Groth16Prove on 2^10 constraints:
+        // 0.23 of the quotient's 0.37 ms).  The three convolutions share the kernel 1/d, so they run as one batch of four
+        // transforms (the fourth is zeros: batches are powers of two) -- one pair of launches instead of three.
+        const int logL = qt.lognp + 1;
+        hipLaunchKernelGGL(k_lagrange_weights3, dim3(nblk(4 * L)), dim3(256), 0, st, qt.s4, FrPtr3{{yA, yB, yC}}, qt.invfact, n, logL);
+        NttFuse f;
+        f.st = NTT_ST_MUL; f.st_aux = qt.rhat; f.aux_mask = L - 1;
+        QT_TRY(ntt_run<false>(tabs, st, qt.s4, 4 * L, logL, f));
+        QT_TRY(ntt_run<true>(tabs, st, qt.s4, 4 * L, logL));
+        for (int k = 0; k < 3; k++) S[k] = qt.s4 + (u64)k * L;
+    } else
     for (int k = 0; k < 3; k++) {
         hipLaunchKernelGGL(k_lagrange_weights, dim3(nblk(L)), dim3(256), 0, st, S[k], ys[k], qt.invfact, n, L);
         NttFuse f;
@@ -503,6 +532,7 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.scratch, big));
     QT_TRY(qt_alloc(qt, &qt.pa, big));
     QT_TRY(qt_alloc(qt, &qt.pb, big));
+    if (2 * np <= QT_BATCH_MAX_L) QT_TRY(qt_alloc(qt, &qt.s4, 8 * np));
     QT_TRY(qt_alloc(qt, &qt.z, n + 1));
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
     // ---- factorials up to 2np - 1 (host; ps_qap_create computes them on a thread of its own) ----

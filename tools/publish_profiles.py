@@ -25,7 +25,7 @@ rec = {
     "hbm_bytes_per_launch_if_fetch_doubled": (2 * fetch + write) * 1024,
     "algorithmic_bytes_per_launch": 1 << 27,
     "expected_gather_plus_stores": 13 * (1 << 20) * 128 + 1.05 * (1 << 19) * 224 + 2 * 13 * (1 << 20) / 32 * 224 * 0.5,
-    "measured_at": "round 2, commit %s (the kernels of this commit)" % commit,
+    "measured_at": "round 3, commit %s (the kernels of this commit)" % commit,
     "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), KB units, tools/collect_profiles.sh.  The gather reads one "
             "128-byte table row per entry (13.6 M entries = 1.74 GB); FETCH_SIZE reports ~1.1 GB raw -- between the guide's 'half "
             "of a wide coalesced read' and the full count: this access width (7 x 16 B per lane out of a 128-byte row) is "
