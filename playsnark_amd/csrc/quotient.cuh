@@ -96,14 +96,16 @@ __device__ inline Fr fr_sub_mul_small_div_2p28(const Fr& up, const Fr& coef, u32
 // Montgomery step, see above) instead of a full field multiplication.  To keep every term at the same
 // scale, d[64b+L] is divided by 2^28 once per step before it enters (lanes L < k in step k), so all terms
 // end with the factor 2^(-28*63); `unscale` = 2^(28*63) (Montgomery form) removes it.
-__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off, Fr unscale) {
+// A batch of conversions (the two interpolations of a small circuit, interpolate2_on_1_to_n): `member64` blocks per member,
+// the nodes start again at off + 1 for every member.
+__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off, Fr unscale, u32 member64) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nblocks64) return;
     const u64 base = 64ull * wave;
     Fr mine = d[base + lane];
     Fr coef = fr_zero();
-    u32 c = (u32)(off + base + 64);  // node of step k = 63
+    u32 c = (u32)(off + 64ull * (wave % member64) + 64);  // node of step k = 63
     for (int k = 63; k >= 0; k--) {
         Fr up = fr_shfl_up1(coef);
         Fr dk = fr_shfl(mine, k);
@@ -366,24 +368,25 @@ static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
 
 // Newton coefficients on the nodes off+1, off+2, .. (np of them, zero beyond the true length) -> monomial
 // coefficients, in place
+// `members` (a power of two) conversions at once: data and scratch hold members x np elements, every member on the same nodes
 static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, u64 np, int lognp, const std::vector<Fr*>& zhat,
-                                            u64 off, Fr* data, Fr* scratch) {
+                                            u64 off, Fr* data, Fr* scratch, u64 members = 1) {
     Fr unscale = fr_from_u64(1ull << 28);  // 2^(28*63), Montgomery form
     {
         const Fr two28 = unscale;
         for (int i = 1; i < 63; i++) unscale = fr_mul(unscale, two28);
     }
-    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np)), dim3(256), 0, st, data, (u32)(np / 64), off, unscale);
+    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np * members)), dim3(256), 0, st, data, (u32)(np * members / 64), off, unscale, (u32)(np / 64));
     for (int logs = 7; logs <= lognp; logs++) {
         // scratch = NTT(upper halves of the nodes, zero-padded) * zhat ; data = lower halves + INTT(scratch):
         // prepare, multiply and combine ride on the first load / last store of the two transforms
         NttFuse f;
         f.ld = NTT_LD_UPPER_HALF; f.ld_src = data; f.logs = logs;
-        f.st = NTT_ST_MUL; f.st_aux = zhat[logs];
-        QT_TRY(ntt_run<false>(tabs, st, scratch, np, logs, f));
+        f.st = NTT_ST_MUL; f.st_aux = zhat[logs]; f.aux_mask = np - 1;
+        QT_TRY(ntt_run<false>(tabs, st, scratch, np * members, logs, f));
         NttFuse g;
         g.st = NTT_ST_COMBINE; g.st_dst = data; g.logs = logs;
-        QT_TRY(ntt_run<true>(tabs, st, scratch, np, logs, g));
+        QT_TRY(ntt_run<true>(tabs, st, scratch, np * members, logs, g));
     }
     return hipGetLastError();
 }
@@ -406,6 +409,37 @@ static inline hipError_t interpolate_on_nodes(const NttTables& tabs, hipStream_t
 // values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
 static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y) {
     return interpolate_on_nodes(tabs, st, qt, y, qt.n, qt.np, qt.lognp, qt.vhat, qt.zhat, 0);
+}
+
+// Two interpolations on {1..n} as ONE batch (small circuits, where a transform is a handful of workgroups and every launch is
+// latency; qt.s4 = [t1: 2 x 2np | data: 2 x np | scratch: 2 x np]): the coefficients of member b end up in data[b * np ..].
+__global__ void __launch_bounds__(256) k_interp_prep2(Fr* __restrict__ out, const Fr* __restrict__ y0, const Fr* __restrict__ y1,
+                                                      const Fr* __restrict__ invfact, u64 cnt, int logL) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (2ull << logL)) return;
+    const u64 i = idx & ((1ull << logL) - 1);
+    out[idx] = i < cnt ? fr_mul((idx >> logL) ? y1[i] : y0[i], invfact[i]) : fr_zero();
+}
+__global__ void __launch_bounds__(256) k_interp_take2(Fr* __restrict__ data, const Fr* __restrict__ t1, u64 cnt, int lognp) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (2ull << lognp)) return;
+    const u64 i = idx & ((1ull << lognp) - 1), b = idx >> lognp;
+    data[idx] = i < cnt ? t1[(b << (lognp + 1)) + i] : fr_zero();
+}
+static inline hipError_t interpolate2_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y0, const Fr* y1,
+                                                Fr* out0, Fr* out1) {
+    const u64 np = qt.np, L = 2 * np;
+    Fr *t1 = qt.s4, *data = qt.s4 + 2 * L, *scratch = data + 2 * np;
+    hipLaunchKernelGGL(k_interp_prep2, dim3(nblk(2 * L)), dim3(256), 0, st, t1, y0, y1, (const Fr*)qt.invfact, qt.n, qt.lognp + 1);
+    NttFuse f;
+    f.st = NTT_ST_MUL; f.st_aux = qt.vhat; f.aux_mask = L - 1;
+    QT_TRY(ntt_run<false>(tabs, st, t1, 2 * L, qt.lognp + 1, f));
+    QT_TRY(ntt_run<true>(tabs, st, t1, 2 * L, qt.lognp + 1));
+    hipLaunchKernelGGL(k_interp_take2, dim3(nblk(2 * np)), dim3(256), 0, st, data, (const Fr*)t1, qt.n, qt.lognp);
+    QT_TRY(newton_to_monomial(tabs, st, np, qt.lognp, qt.zhat, 0, data, scratch, 2));
+    QT_TRY(hipMemcpyAsync(out0, data, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
+    QT_TRY(hipMemcpyAsync(out1, data + np, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
+    return hipGetLastError();
 }
 
 // h alone (PHGR13Prove and QAP.Quotient need no A, B coefficients): with y_P = P(1..n),

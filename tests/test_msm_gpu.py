@@ -742,6 +742,8 @@ def test_tail_of_a_sum_chains_and_trees_give_the_oracle_bytes(ps_api, ctx, co, p
     vectors = [[rng.fr() for _ in range(n)],
                [k] * n,                                                     # one bucket per window holds everything
                [int(rng.next() & 1) for _ in range(n)],                     # wire values of a boolean circuit
+               [1 if i & 1 else rng.fr() for i in range(n)],                # half ones: ONE heavy bucket among ordinary ones (the
+                                                                            # quad-tree heavy kernels of a short sum, qtail.cuh)
                [0] * n]
     try:
         for vi, sc in enumerate(vectors):
