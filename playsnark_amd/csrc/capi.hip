@@ -119,6 +119,8 @@ struct ps_ctx {
     uint8_t g16_fixed[96 * 3 + 192 * 2] = {0};
     ps_points *g16_pa = nullptr, *g16_pb = nullptr, *g16_pc = nullptr;
     bool g16_tabs = false;           // whether window tables were wanted when the arrays above were made
+    bool g16_split = false;          // ... and whether PC was made for the split form of C (prove.inc, groth16_prove_impl)
+    size_t g16_b1_min_n = (size_t)1 << 19;  // Lagrange-form keys of this many constraints or more: B in G1 as a sum of its own (PS_G16_B1_MIN_N)
     hipEvent_t g16_ready = nullptr;
     // PHGR13 driver: vbs + wbs + ybs summed pointwise once per evaluation key (gz, pinochio.go:239-242)
     unsigned long long phgr_key[3] = {0, 0, 0};
@@ -213,6 +215,7 @@ extern "C" int ps_ctx_create(int device, ps_ctx** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(PS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", library is built for gfx950 only");
     ps_ctx* c = new ps_ctx();
+    if (const char* e = getenv("PS_G16_B1_MIN_N")) c->g16_b1_min_n = (size_t)strtoull(e, nullptr, 10);  // tests / measurements
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {

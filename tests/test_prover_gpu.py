@@ -554,6 +554,38 @@ def test_qap_is_valid_is_the_reference_divisibility_test(ps_api, ctx, pr):
         q.IsValid(ps_api.Poly.upload(ctx, sol[:-1]))
 
 
+def test_groth16_split_form_of_c_gives_the_oracle_proof(ps_api, co, pr, monkeypatch):
+    """With a Lagrange-form key and >= 2^19 constraints Groth16Prove sums B in G1 on its own (over Xi with the values b_j,
+    which are wire values: small in most of a real circuit) and adds s A + r B1 to C on the host, instead of one sum with
+    the full-width scalars s a_j + r b_j (prove.inc, groth16_prove_impl; groth16.go:180-205 is the statement restated).
+    The environment moves the threshold so that the form runs at a size the oracle proves in seconds: the same bytes for
+    the whole proof, for an int64 witness (NioLP as a sum of its own) and for the shares of 3 ranks folded."""
+    from oracle import restate as rs
+    from playsnark_amd.dist import ShardedGroth16
+
+    rng = pr.SplitMix64(SEED + 1919)
+    for kind in ("synthetic", "bits"):
+        c, sol = rs.synthetic_circuit(300) if kind == "synthetic" else rs.bit_circuit(257, seed=5)
+        c = rs.SparseR1CS(c.nbVars, c.nbVars - (3 if kind == "synthetic" else 1), c.left, c.right, c.out)
+        tw = [rng.fr() for _ in range(5)]
+        r, s = rng.fr(), rng.fr()
+        want = rs.groth16_prove(rs.groth16_setup(c, *tw), c, sol, r, s, fast=True)
+        for min_n in ("2", "1000000000"):
+            monkeypatch.setenv("PS_G16_B1_MIN_N", min_n)
+            cx = ps_api.Context(0)
+            q = _upload_circuit(ps_api, cx, c)
+            tr, _ = ps_api.NewGroth16TrustedSetup(q, *tw)
+            for dsol in [ps_api.Poly.upload(cx, sol)] + ([ps_api.Poly.from_values(cx, sol)] if kind == "bits" else []):
+                for key in (tr, tr.monomial_only()):
+                    got = ps_api.Groth16Prove(key, q, dsol, r, s)
+                    assert (got.A, got.B, got.C) == (want.A, want.B, want.C), (kind, min_n)
+            sh = ShardedGroth16(cx, None, 3, 0)
+            dsol = ps_api.Poly.upload(cx, sol)
+            folded = sh.fold([sh.partials(tr, q, dsol, r, s, rank=g) for g in range(3)], r, s)
+            assert (folded.A, folded.B, folded.C) == (want.A, want.B, want.C), (kind, min_n, "shares")
+            cx.close()
+
+
 def test_one_key_two_contexts_two_threads_same_proof(ps_api, co, pr):
     """A proving key uploaded once and used from two host threads, each with its own context and QAP, as the reference's
     pure Groth16Prove / PHGR13Prove allow (groth16.go:122, pinochio.go:207): the window tables the provers attach to the
