@@ -990,8 +990,8 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const size_t max_heavy = (size_t)(total / (heavy_slices * (u64)pl.M)) + 2;
     // heavy: [count][bucket list: max_heavy][job_base: max_heavy + 1]; hparts: one point per job
     if ((rc = wc->heavy.ensure(4 * (2 * max_heavy + 2)))) return rc;
-    const u32 heavy_chunk = qfix ? 256 / QTraits<KF>::GL : HEAVY_CHUNK;  // slices per job
-    const size_t max_jobs = (size_t)nthreads_acc / heavy_chunk + max_heavy + 1;
+    const u32 heavy_npb = 256 / QTraits<KF>::GL;  // a job is at least one block's worth of slices (heavy_chunk_of)
+    const size_t max_jobs = (size_t)nthreads_acc / heavy_npb + max_heavy + 1;
     if ((rc = wc->hparts.ensure(sizeof(Xyzz<F>) * max_jobs))) return rc;
     if (sizeof(Xyzz<F>) * (pl.sets > 1 ? (size_t)pl.sets : (size_t)nres) + 16 > PS_PINNED_SLOT) return fail(PS_ERR_ARG, "too many windows");
     hipStream_t st = wc->stream;
@@ -1002,7 +1002,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     PS_STAGE_MARK();  // 4: buffers cleared and the previous sum's accumulation done ("queue")
     constexpr bool PF = LN == 1 || PS_G2_ACC_WAVES == 1;  // next point prefetched (the lane-pair G2 kernel at two waves per SIMD has no registers to spare)
     hipLaunchKernelGGL((k_accumulate<KF, PF>), dim3(nblocks((size_t)nthreads_acc * LN)), dim3(256), 0, st, src,
-                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, idx_mask, w_stride, pstride,
+                       (const u32*)c->sorted.p, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc, idx_mask, w_stride, pstride,
                        (Xyzz<F>*)wc->buckets.p, (Xyzz<F>*)wc->parts.p, (u32*)wc->heavy.p);
     if (acc_done) HIP_TRY(hipEventRecord(acc_done, st));
     PS_STAGE_MARK();  // 5: after accumulate
@@ -1016,26 +1016,22 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         // quads of a bucket must fit THIS group's 256-thread block (64 G1 points, 32 G2 points)
         const u32 lpb = qlpb;
         hipLaunchKernelGGL(k_qfixup<KF>, dim3(nblocks(G * (u64)lpb * QTraits<KF>::GL)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
-                           lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
+                           nthreads_acc, lpb, (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     } else
-    hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M,
+    hipLaunchKernelGGL(k_fixup<KF>, dim3(nblocks(G * LN)), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc,
                        (const Xyzz<F>*)wc->parts.p, (Xyzz<F>*)wc->buckets.p, (u32*)wc->heavy.p, (u32*)wc->heavy.p + 1);
     {
         const u32* hcount = (const u32*)wc->heavy.p;
         const u32* hlist = hcount + 1;
         u32* job_base = (u32*)wc->heavy.p + 1 + max_heavy;
-        hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, hcount, hlist, job_base, heavy_chunk);
-        if (qfix) {  // short sums: two levels of quad trees (qtail.cuh)
-            hipLaunchKernelGGL(k_qfixup_heavy_part<KF>, dim3(1024), dim3(256), 0, st, (const u32*)c->offs.p, pl.M, (const Xyzz<F>*)wc->parts.p,
-                               hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
-            hipLaunchKernelGGL(k_qfixup_heavy<KF>, dim3(256), dim3(256), 0, st, (const Xyzz<F>*)wc->hparts.p, (Xyzz<F>*)wc->buckets.p, hcount,
-                               hlist, (const u32*)job_base);
-        } else {
-        hipLaunchKernelGGL(k_fixup_heavy_part<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const u32*)c->offs.p, pl.M,
-                           (const Xyzz<F>*)wc->parts.p, hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
-        hipLaunchKernelGGL(k_fixup_heavy<KF>, dim3(256), dim3(256), (256 / LN) * sizeof(Xyzz<F>), st, (const Xyzz<F>*)wc->hparts.p,
-                           (Xyzz<F>*)wc->buckets.p, hcount, hlist, (const u32*)job_base);
-        }
+        hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc, hcount, hlist, job_base, heavy_npb);
+        // two levels of quad trees for every plan (qtail.cuh): the one-lane kernels of rounds 1-2 (jobs of 1024 slices, strided
+        // chains, an 8-level LDS tree of 14-36 us additions) took 0.43 ms for the 2^19 ones of a boolean witness at 2^20 points
+        hipLaunchKernelGGL(k_qfixup_heavy_part<KF>, dim3(1024), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc,
+                           (const Xyzz<F>*)wc->parts.p,
+                           hcount, hlist, (const u32*)job_base, (Xyzz<F>*)wc->hparts.p);
+        hipLaunchKernelGGL(k_qfixup_heavy<KF>, dim3(256), dim3(256), 0, st, (const Xyzz<F>*)wc->hparts.p, (Xyzz<F>*)wc->buckets.p, hcount,
+                           hlist, (const u32*)job_base);
     }
     PS_STAGE_MARK();  // 6: after fixup
     {

@@ -774,6 +774,20 @@ __device__ inline void block_tree_sum(Xyzz<typename FieldTraits<KF>::Store>* sm,
 // ---------------------------------------------------------------------------------------
 // 4. bucket accumulation over fixed slices of the sorted entry list
 // ---------------------------------------------------------------------------------------
+// Slice length a sum actually uses.  The plan is made before the sort has run, for W digits per scalar; a witness of bits or
+// small values leaves one digit per scalar, and 2^19 entries in slices of 32 are 256 waves on a chip that holds 2 048 (the
+// accumulation of Groth16's A over 2^20 booleanity gates: 0.46-0.60 ms for 0.06 ms of work).  So every kernel that walks the
+// slices derives their length from the length of the sorted list E = offs[G], the planned slice count T and the planned M:
+// M again as soon as the list is a quarter of the plan, shorter below, never under 4 (or a shorter planned M).
+__device__ inline int eff_slice(u32 E, u32 T, int M) {
+#if defined(PS_NO_EFF_SLICE)  // measurement builds: the planned length throughout
+    return M;
+#endif
+    const u64 m = (4ull * E + T - 1) / (T ? T : 1u);
+    const u64 lo = M < 4 ? (u64)M : 4ull;
+    return m >= (u64)M ? M : (int)(m < lo ? lo : m);
+}
+
 template <class F>
 PS_INL bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }  // stored points are canonical
 
@@ -826,11 +840,12 @@ __device__ inline void next_bucket(const u32* __restrict__ offs, u32 G, u32 p, u
 template <class KF, bool PREFETCH>
 __global__ void __launch_bounds__(256, PS_ACC_WAVES(KF)) k_accumulate(const char* __restrict__ points,
                                                        const u32* __restrict__ sorted, const u32* __restrict__ offs,
-                                                       u32 G, int M, u32 idx_mask, u64 w_stride, u32 pstride,
+                                                       u32 G, int Mplan, u32 T, u32 idx_mask, u64 w_stride, u32 pstride,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                        u32* __restrict__ heavy_count) {
     const u32 E = offs[G];
+    const int M = eff_slice(E, T, Mplan);
     const u32 t = logical_tid<KF>();
     if (blockIdx.x == 0 && threadIdx.x == 0) *heavy_count = 0;  // the fix-up's list of heavy buckets starts empty (no memset launch)
     const u64 start64 = (u64)t * (u64)M;
@@ -902,15 +917,16 @@ constexpr u32 HEAVY_SPAN = 8;  // buckets cut into more slices than this go to t
 #endif
 
 template <class KF>
-__global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restrict__ offs, u32 G, int M,
+__global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restrict__ offs, u32 G, int Mplan, u32 T,
                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
     u32 g = logical_tid<KF>();
     if (g >= G) return;
+    const int M = eff_slice(offs[G], T, Mplan);
     u32 lo = offs[g], hi = offs[g + 1];
     if (lo == hi) {  // empty bucket: the identity (no memset of the bucket array: every bucket is written by exactly one of the
-                     // accumulation's flush, this kernel and k_fixup_heavy)
+                     // accumulation's flush, this kernel and k_qfixup_heavy)
         st_xyzz<KF>(&buckets[g], xyzz_identity<KF>());
         return;
     }
@@ -932,14 +948,23 @@ __global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restr
 
 // Heavy buckets (skewed scalars: a witness that is half ones puts n/2 entries into one bucket).  The
 // partial slots of the slices t0..t1 of such a bucket are summed in two levels: the slices are cut into
-// jobs of HEAVY_CHUNK, any workgroup takes any job (strided serial sums, then an LDS tree), and a last
-// kernel adds up the job results of each bucket.  The dependency chain is HEAVY_CHUNK/256 + 8 additions
-// per level whatever the skew, and a single enormous bucket still uses the whole chip.
-constexpr u32 HEAVY_CHUNK = 1024;
+// jobs, any workgroup takes any job (strided sums, then a tree), and a last kernel adds up the job results
+// of each bucket -- k_qfixup_heavy_part / k_qfixup_heavy in qtail.cuh, on lane quads.  The dependency chain
+// is ~2 (s + 6) quad additions whatever the skew (heavy_chunk_of), and a single enormous bucket still uses the chip.
+constexpr u32 HEAVY_CHUNK = 1024;  // (job size of the one-lane kernels of rounds 1-2; k_heavy_jobs keeps it for npb = 0)
+// Slices per job of a heavy bucket that spans `span` slices, for the quad-tree kernels (qtail.cuh; npb = partial sums per block:
+// 64 G1, 32 G2): npb * s with s = ceil(sqrt(span) / npb), so that both levels -- a job's s strided additions and a tree of
+// log2(npb), then the same over the bucket's ~sqrt(span) jobs -- are equally deep whatever the size of the bucket.
+__host__ __device__ inline u32 heavy_chunk_of(u32 span, u32 npb) {
+    u32 s = 1;
+    while ((u64)s * s * npb * npb < span) s++;
+    return npb * s;
+}
 
 // job_base[h] = number of jobs of the heavy buckets before h; job_base[nheavy] = total.  One workgroup.
-__global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs, int M, const u32* __restrict__ heavy_count,
-                                                    const u32* __restrict__ heavy_list, u32* __restrict__ job_base, u32 chunk) {
+__global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs, u32 G, int Mplan, u32 T, const u32* __restrict__ heavy_count,
+                                                    const u32* __restrict__ heavy_list, u32* __restrict__ job_base, u32 npb) {
+    const int M = eff_slice(offs[G], T, Mplan);
     __shared__ u32 wsum[4];
     const u32 nheavy = *heavy_count;
     const u32 tid = threadIdx.x;
@@ -950,6 +975,7 @@ __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs
         if (h < nheavy) {
             const u32 g = heavy_list[h];
             const u32 t0 = offs[g] / (u32)M, t1 = (offs[g + 1] - 1) / (u32)M;
+            const u32 chunk = npb ? heavy_chunk_of(t1 - t0 + 1, npb) : HEAVY_CHUNK;
             cnt = (t1 - t0 + chunk) / chunk;  // ceil((t1 - t0 + 1) / chunk)
         }
         u32 inc = wave_incl_scan(cnt);
@@ -967,63 +993,8 @@ __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs
     if (tid == 0) job_base[nheavy] = running;
 }
 
-template <class KF>
-__global__ void __launch_bounds__(256) k_fixup_heavy_part(const u32* __restrict__ offs, int M,
-                                                          const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
-                                                          const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
-                                                          const u32* __restrict__ job_base,
-                                                          Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    typedef typename FieldTraits<KF>::Store S;
-    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 nheavy = *heavy_count;
-    if (nheavy == 0) return;
-    const u32 njobs = job_base[nheavy];
-    for (u32 j = blockIdx.x; j < njobs; j += gridDim.x) {
-        u32 lo_h = 0, hi_h = nheavy;  // job_base[lo_h] <= j < job_base[hi_h]
-        while (hi_h - lo_h > 1) {
-            u32 mid = (lo_h + hi_h) >> 1;
-            if (job_base[mid] <= j) lo_h = mid; else hi_h = mid;
-        }
-        const u32 g = heavy_list[lo_h];
-        const u32 lo = offs[g], hi = offs[g + 1];
-        const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
-        const u32 ts = t0 + (j - job_base[lo_h]) * HEAVY_CHUNK;
-        const u32 te = (t1 - ts >= HEAVY_CHUNK) ? ts + HEAVY_CHUNK - 1 : t1;
-        Xyzz<KF> acc = xyzz_identity<KF>();
-        for (u32 t = ts + logical_local<KF>(); t <= te; t += logical_block<KF>()) {
-            u32 slice_start = t * (u32)M;
-            u32 rs = lo > slice_start ? lo : slice_start;
-            Xyzz<KF> part = ld_xyzz<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
-            xyzz_add_inl<KF>(acc, part);
-        }
-        block_tree_sum<KF>(sm, acc);
-        if (logical_local<KF>() == 0) st_xyzz<KF>(&hparts[j], ld_xyzz<KF>(&sm[0]));
-        __syncthreads();
-    }
-}
-
-template <class KF>
-__global__ void __launch_bounds__(256) k_fixup_heavy(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts,
-                                                     Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
-                                                     const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
-                                                     const u32* __restrict__ job_base) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    typedef typename FieldTraits<KF>::Store S;
-    Xyzz<S>* sm = reinterpret_cast<Xyzz<S>*>(smem_raw);
-    const u32 nheavy = *heavy_count;
-    for (u32 h = blockIdx.x; h < nheavy; h += gridDim.x) {
-        const u32 j0 = job_base[h], j1 = job_base[h + 1];
-        Xyzz<KF> acc = xyzz_identity<KF>();
-        for (u32 j = j0 + logical_local<KF>(); j < j1; j += logical_block<KF>()) {
-            Xyzz<KF> part = ld_xyzz<KF>(&hparts[j]);
-            xyzz_add_inl<KF>(acc, part);
-        }
-        block_tree_sum<KF>(sm, acc);
-        if (logical_local<KF>() == 0) st_xyzz<KF>(&buckets[heavy_list[h]], ld_xyzz<KF>(&sm[0]));
-        __syncthreads();
-    }
-}
+// (The one-lane kernels that summed a heavy bucket's jobs in rounds 1-2 -- strided chains and an LDS tree per job of 1024
+// slices -- are gone: every plan uses the two levels of quad trees in qtail.cuh, k_qfixup_heavy_part / k_qfixup_heavy.)
 
 // ---------------------------------------------------------------------------------------
 // 6. bucket reduction: window sum = sum_{b=0}^{NB-1} (b+1) * B[b]

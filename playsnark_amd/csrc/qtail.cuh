@@ -180,12 +180,13 @@ __device__ inline void q_block_tree(Fp* sm, KF& mine, u32 pt, u32 grp) {
 // follows.  Buckets that span more than QFIX_HEAVY x LPB slices go to the heavy-bucket kernels (msm.cuh section 5).
 constexpr u32 QFIX_HEAVY = 16;  // (4: buckets a little above the average went heavy by the thousand -- Groth16 on 2^14 constraints 1.7 -> 2.1 ms)
 template <class KF>
-__global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u32 G, int M, u32 LPB,
+__global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u32 G, int Mplan, u32 T, u32 LPB,
                                                 const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                 Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                 u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
     constexpr u32 GL = QTraits<KF>::GL;
     __shared__ Fp sm[256];
+    const int M = eff_slice(offs[G], T, Mplan);
     const u32 pt = threadIdx.x / GL;
     const u64 gp = (u64)blockIdx.x * (256 / GL) + pt;
     const u32 g = (u32)(gp / LPB), sub = (u32)(gp % LPB);
@@ -217,9 +218,9 @@ __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u3
     if (store && sub == 0) q_store<KF>(&buckets[g], acc);
 }
 
-// ---- heavy buckets of a short sum (a witness that is half ones puts n/2 digits into one bucket; slices are 2..32 entries) ----
-// Two levels of quad trees: jobs of one block's worth of slices (64 G1 / 32 G2 partial sums, one per quad, a tree as deep as
-// the job is long), then per bucket a tree over its jobs' results.  512 partial sums of a G2 bucket (Groth16's B on 2^12
+// ---- heavy buckets (a witness that is half ones puts n/2 digits into one bucket) ----
+// Two levels of quad trees: jobs of a block's worth of slices (64 G1 / 32 G2 quads; s partial sums per quad for the largest
+// buckets, heavy_chunk_of), a tree as deep as the job is long, then per bucket the same over its jobs' results.  512 partial sums of a G2 bucket (Groth16's B on 2^12
 // constraints of the tiled toy circuit): 5 + 4 quad additions deep, 0.10 ms, where the one-lane kernels of the long sums
 // (k_fixup_heavy_part: strided chains, then a 7-level tree of 20 us lane-pair additions) took 0.31 ms.
 template <class KF>
@@ -230,7 +231,7 @@ __device__ inline u32 q_tree_size(u32 count) {  // the power of two >= count, at
     return g;
 }
 template <class KF>
-__global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict__ offs, int M,
+__global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict__ offs, u32 G, int Mplan, u32 T,
                                                             const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                             const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
                                                             const u32* __restrict__ job_base,
@@ -239,6 +240,7 @@ __global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict
     __shared__ Fp sm[256];
     const u32 nheavy = *heavy_count;
     if (nheavy == 0) return;
+    const int M = eff_slice(offs[G], T, Mplan);
     const u32 njobs = job_base[nheavy];
     const u32 pt = threadIdx.x / GL;
     for (u32 j = blockIdx.x; j < njobs; j += gridDim.x) {
@@ -250,13 +252,15 @@ __global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict
         const u32 g = heavy_list[lo_h];
         const u32 lo = offs[g], hi = offs[g + 1];
         const u32 t0 = lo / (u32)M, t1 = (hi - 1) / (u32)M;
-        const u32 ts = t0 + (j - job_base[lo_h]) * NPB;  // jobs of NPB slices (k_heavy_jobs with chunk = NPB)
-        const u32 te = (t1 - ts >= NPB) ? ts + NPB - 1 : t1;
+        const u32 chunk = heavy_chunk_of(t1 - t0 + 1, NPB);  // as k_heavy_jobs cut the bucket
+        const u32 ts = t0 + (j - job_base[lo_h]) * chunk;
+        const u32 te = (t1 - ts >= chunk) ? ts + chunk - 1 : t1;
         KF acc = f_zero((const KF*)0);
-        if (ts + pt <= te) {
-            const u32 t = ts + pt, slice_start = t * (u32)M;
+        for (u32 t = ts + pt; t <= te; t += NPB) {
+            const u32 slice_start = t * (u32)M;
             const u32 rs = lo > slice_start ? lo : slice_start;
-            acc = q_load<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
+            const KF p = q_load<KF>(&parts[2 * (size_t)t + (rs == slice_start ? 0 : 1)]);
+            q_add<KF>(acc, p);
         }
         q_block_tree<KF>(sm, acc, pt, q_tree_size<KF>(te - ts + 1));
         if (pt == 0) q_store<KF>(&hparts[j], acc);
