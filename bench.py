@@ -398,7 +398,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend_used == "nccl" else "cpu")  # (after a fallback the group is gloo whatever --backend said)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = ctx.last_msm_info()
