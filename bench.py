@@ -661,12 +661,16 @@ def extras(api, ctx, args, mad_peak):
     sm_mono_ms, _, _ = timed_g16_on(api, ctx, tr.monomial_only(), q, dsol, r, s, reps=10)
     sm_ms, sm_ph, _ = timed_g16_on(api, ctx, tr, q, dsol, r, s, reps=10)
     ek, pvk = api.NewPHGR13TrustedSetup(q, *[fr() for _ in range(8)])
-    api.PHGR13Prove(ek, q, dsol)
-    t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(2):  # tables on the first call, the workers' workspaces on the second
         api.PHGR13Prove(ek, q, dsol)
-    sm_p_ms = (time.perf_counter() - t0) / 10 * 1e3
-    out["provers_2p10"] = {"groth16_ms": sm_ms, "groth16_phase_ms": avg(sm_ph), "groth16_monomial_key_ms": sm_mono_ms, "phgr13_ms": sm_p_ms}
+    laps = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        api.PHGR13Prove(ek, q, dsol)
+        laps.append((time.perf_counter() - t0) * 1e3)
+    sm_p_ms = sorted(laps)[len(laps) // 2]
+    out["provers_2p10"] = {"groth16_ms": sm_ms, "groth16_phase_ms": avg(sm_ph), "groth16_monomial_key_ms": sm_mono_ms, "phgr13_ms": sm_p_ms,
+                           "note": "Groth16: mean of 10 proofs after one warm-up; PHGR13: median of 10 after two"}
     del tr, vk, ek, pvk, q, dsol
 
     # ---- the regime the reference itself lives in (Vector = []int, algebra.go:13): 2^20 booleanity gates b*b = b, a witness
