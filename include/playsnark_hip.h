@@ -246,7 +246,10 @@ typedef struct { /* the prover's part of Groth16Setup (groth16.go:30-61) */
 } ps_groth16_pk;
 /* Groth16Prove (groth16.go:122-211).  r, s are inputs (the reference draws them at :148,:158 and
  * keeps them in the proof, :203-206).  diff = n_vars - n_io is used as the first non-IO index
- * exactly as the reference does (groth16.go:175-177). */
+ * exactly as the reference does (groth16.go:175-177).
+ * Internal forms, all giving the same group elements: C as one sum with the scalars s a_j + r b_j, or -- Lagrange-form keys
+ * of >= 2^19 constraints -- B in G1 as a sum of its own over the wire values and s A + r B1 added on the host (DESIGN.md
+ * section 5; PS_G16_B1_MIN_N in the environment of ps_ctx_create moves that threshold: a knob for tests and measurements). */
 int ps_groth16_prove(ps_ctx* ctx, const ps_groth16_pk* pk, const ps_qap* q, const ps_scalars* sol,
                      const uint8_t r_be32[32], const uint8_t s_be32[32], uint8_t A[96], uint8_t B[192],
                      uint8_t C[96]);
