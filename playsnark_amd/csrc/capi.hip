@@ -894,6 +894,9 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     if (G <= SORT_MAX_BUCKETS) {  // two-level counting sort, no per-entry global atomics (msm.cuh 1'-3')
         int fb = 5;  // fine bits: as few as keep the coarse bins within SORT_MAX_COARSE
         while (((G + (1ull << fb) - 1) >> fb) > SORT_MAX_COARSE) fb++;
+#if defined(PS_TAIL_TUNE)
+        if (const char* e = getenv("PS_T_FB")) fb = std::max(fb, std::min(atoi(e), 10));
+#endif
         const u32 ncoarse = (u32)((G + (1ull << fb) - 1) >> fb);
         if ((rc = c->coarse.ensure(4 * (4 * (size_t)SORT_MAX_COARSE + 8)))) return rc;
         u32* coarse_cnt = (u32*)c->coarse.p;
@@ -903,7 +906,8 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
         HIP_TRY(hipMemsetAsync(coarse_cnt, 0, 4 * SORT_MAX_COARSE, st));
         const bool may_have_big_bins = total > SORT_BIG;  // a bin of more than SORT_BIG entries needs that many digits
         if (may_have_big_bins) HIP_TRY(hipMemsetAsync(c->counts.p, 0, 4 * G, st));  // per-bucket counters of the big bins (k_sort_big_*)
-        hipLaunchKernelGGL(k_sort_count, dgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
+        const dim3 cgrid((unsigned)((n + (size_t)COUNT_PER_THREAD * DIGITS_THREADS - 1) / ((size_t)COUNT_PER_THREAD * DIGITS_THREADS)));
+        hipLaunchKernelGGL(k_sort_count, cgrid, dim3(DIGITS_THREADS), 0, st, scalars_ptr(sc), (u32)n, pl.c, pl.W, pl.NB, cadd, fold_neg,
                            single, ncoarse, fb, (u32*)c->ranks.p, coarse_cnt);
         PS_STAGE_MARK();  // 1: after digits + coarse histogram
         hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(SORT_MAX_COARSE), 0, st, (const u32*)coarse_cnt, ncoarse, coarse_off, coarse_cur,

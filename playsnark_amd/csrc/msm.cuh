@@ -373,17 +373,14 @@ constexpr u32 SORT_MAX_COARSE = 1024;
 constexpr u64 SORT_MAX_BUCKETS = (u64)SORT_FINE * SORT_MAX_COARSE;
 static_assert(DIGITS_THREADS == (int)SORT_MAX_COARSE && SORT_FINE == SORT_MAX_COARSE, "one thread per histogram bin");
 
-// digit of scalar i in window w: (magnitude - 1) | sign << 31, or 0xffffffff for a zero digit (see k_digits_grouped)
-__device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, int W, int w, u32 NB, const DigitConst& cadd,
-                                 int fold_neg) {
-    const u32 mask = (1u << c) - 1u;
-    const int bit = w * c, li = bit >> 5, sh = bit & 31;
-    const bool top = w == W - 1;
-    u32 k[8];
+// k' = k + C of scalar i (DigitConst: the signed digits of k are the windows of k' minus NB, independently of each other);
+// a negative witness value r - |v| is folded to |v| with `flip` = the sign bit its digits' codes get
+__device__ inline void scalar_plus_c(const u32* __restrict__ scalars, u32 i, const DigitConst& cadd, int fold_neg, u32 (&k)[8], u32& carry,
+                                     u32& flip) {
     const uint4* sp = reinterpret_cast<const uint4*>(scalars) + 2 * (size_t)i;
     uint4 a = sp[0], b = sp[1];
     k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; k[4] = b.x; k[5] = b.y; k[6] = b.z; k[7] = b.w;
-    u32 flip = 0;
+    flip = 0;
     if (fold_neg && k[7] != 0) {  // r - |v| of a negative witness value: |v| with the point negated
         u32 borrow = 0;
 #pragma unroll
@@ -394,13 +391,19 @@ __device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, 
         }
         flip = 0x80000000u;
     }
-    u32 carry = 0;  // k' = k + C
+    carry = 0;  // k' = k + C
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         u64 t = (u64)k[q] + cadd.w[q] + carry;
         k[q] = (u32)t;
         carry = (u32)(t >> 32);
     }
+}
+// digit of window w from k': (magnitude - 1) | sign << 31, or 0xffffffff for a zero digit (see k_digits_grouped)
+__device__ inline u32 digit_from(const u32 (&k)[8], u32 carry, int c, int W, int w, u32 NB, u32 flip) {
+    const u32 mask = (1u << c) - 1u;
+    const int bit = w * c, li = bit >> 5, sh = bit & 31;
+    const bool top = w == W - 1;
     u64 two = (u64)limb_sel8(k, li) | ((u64)limb_sel8(k, li + 1) << 32);
     if (li == 7) two |= (u64)carry << 32;
     u32 raw = top ? (u32)(two >> sh) : ((u32)(two >> sh) & mask);
@@ -408,6 +411,12 @@ __device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, 
     if (d == 0) return 0xffffffffu;
     u32 mag = d < 0 ? (u32)(-d) : (u32)d;
     return (mag - 1u) | ((d < 0 ? 0x80000000u : 0u) ^ flip);
+}
+__device__ inline u32 digit_code(const u32* __restrict__ scalars, u32 i, int c, int W, int w, u32 NB, const DigitConst& cadd,
+                                 int fold_neg) {
+    u32 k[8], carry, flip;
+    scalar_plus_c(scalars, i, cadd, fold_neg, k, carry, flip);
+    return digit_from(k, carry, c, W, w, NB, flip);
 }
 
 // LDS counter updates with one shortcut: the lanes that share the counter of the wave's first active lane are served by
@@ -449,26 +458,31 @@ __device__ inline u32 lds_rank(u32* ctr, u32 bin, bool active) {
     return pos;
 }
 
+// One pass over the scalars for ALL windows: a thread reads its scalar once and walks its W digits.  (Until round 3 the grid
+// had a row of workgroups per window, each reading the scalars again -- 13 x 32 MB through the Infinity Cache for 2^20
+// full-width scalars: 62 us for a kernel whose own traffic is 86 MB.)
+constexpr int COUNT_PER_THREAD = 2;  // scalars per thread: 2048 per workgroup, 512 workgroups at 2^20
 __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
                                                                DigitConst cadd, int fold_neg, int single_set, u32 ncoarse, int fb,
                                                                u32* __restrict__ codes, u32* __restrict__ coarse_cnt) {
     __shared__ u32 hist[SORT_MAX_COARSE];
-    const int w = blockIdx.y;
-    const u32 chunk_base = blockIdx.x * DIGITS_CHUNK;
     const u32 tid = threadIdx.x;
     hist[tid] = 0;  // DIGITS_THREADS == SORT_MAX_COARSE
     __syncthreads();
-    const u32 key_base = single_set ? 0u : (u32)w * NB;
-#pragma unroll 4
-    for (int j = 0; j < DIGITS_PER_THREAD; j++) {
-        const u32 i = chunk_base + j * DIGITS_THREADS + tid;
-        u32 code = 0xffffffffu;
-        if (i < n) {
-            code = digit_code(scalars, i, c, W, w, NB, cadd, fold_neg);
-            codes[(size_t)w * n + i] = code;
+    for (int j = 0; j < COUNT_PER_THREAD; j++) {
+        const u32 i = (blockIdx.x * COUNT_PER_THREAD + (u32)j) * DIGITS_THREADS + tid;
+        const bool in = i < n;
+        u32 k[8], carry = 0, flip = 0;
+        if (in) scalar_plus_c(scalars, i, cadd, fold_neg, k, carry, flip);
+        for (int w = 0; w < W; w++) {  // uniform trip count: lds_count is called by whole waves
+            u32 code = 0xffffffffu;
+            if (in) {
+                code = digit_from(k, carry, c, W, w, NB, flip);
+                codes[(size_t)w * n + i] = code;
+            }
+            const u32 key_base = single_set ? 0u : (u32)w * NB;
+            lds_count(hist, (key_base + (code & 0x7fffffffu)) >> fb, code != 0xffffffffu);
         }
-        const bool act = code != 0xffffffffu;
-        lds_count(hist, (key_base + (code & 0x7fffffffu)) >> fb, act);
     }
     __syncthreads();
     if (tid < ncoarse && hist[tid]) atomicAdd(&coarse_cnt[tid], hist[tid]);
