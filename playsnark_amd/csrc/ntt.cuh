@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
 // its instruction count alone: with one round of workgroups the chip loads, computes and stores in lock-step, so a
 // 2^20-element pass costs ~12 us + ~18 us of memory phase + 3.5 us per stage, added up (without its butterflies the pass
 // still takes 32-46 us, tools/ntt_tune.sh with -DPS_NTT8_SKIP_BF), and what hides one phase under another is waves per
-// SIMD: this kernel holds 172 / 218 VGPRs (two waves per SIMD), k_ntt_pass 128 (four).  Prefetching the next tile into
+// SIMD: this kernel holds 172 / 218 VGPRs (two waves per SIMD -- which its 40 KB tile per 128 threads would enforce anyway: 4 096
+// resident elements per CU are 512 threads of eight), k_ntt_pass 128 (four).  Prefetching the next tile into
 // registers from a persistent loop made it worse (in-order vmcnt: the first twiddle load waits for the prefetch).  Kept
 // behind the switch as the record of the experiment; DESIGN.md section 6.
 // k_ntt_pass above spends 450 instructions per butterfly for the 250 of its field product: a round trip through LDS and
