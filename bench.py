@@ -412,13 +412,14 @@ def main():
         bytes_per_mul = BYTES_PER_SCALAR_MUL[g]
         achieved = n * bytes_per_mul / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, "profiles", PMC_FILE[g])
-        if os.path.exists(pmc_path) and not strong and args.log2n == 20 and args.scalars == "uniform":
+        pmc_name = PMC_FILE.get(g)  # (no PMC passes were collected for the G2 accumulation: `traffic` stays null there)
+        pmc_path = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else ""
+        if pmc_name and os.path.exists(pmc_path) and not strong and args.log2n == 20 and args.scalars == "uniform":
             try:
                 pmc = json.load(open(pmc_path))
                 traffic = pmc.get("hbm_bytes_per_launch")
                 traffic_source = "rocprofv3 --pmc passes recorded in profiles/%s (%s); not re-measured by this run" % (
-                    PMC_FILE[g], pmc.get("measured_at", "round 1"))
+                    pmc_name, pmc.get("measured_at", "round 1"))
             except Exception:
                 traffic = None
         W, c = info["windows"], info["window_bits"]

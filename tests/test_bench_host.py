@@ -92,3 +92,18 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["points_per_gpu"] == 1 << 14
     assert "2^15 points in total" in line["config"]["workload"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--group", "g2", "--log2n", "12"], ["--group", "g1", "--log2n", "12", "--no-table"],
+                                   ["--group", "g1", "--log2n", "12", "--scalars", "witness"]])
+def test_bench_side_configurations_print_their_line(flags):
+    """The configurations tools/size_sweep.sh and the secondary numbers drive (`--group g2` once died on a missing PMC
+    record after the G2 file name had been dropped from the table): one JSON line, roofline present, traffic null where no
+    PMC pass exists."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-extras", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"] + flags
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] > 0 and line["n_gpus"] == 1 and line["roofline"]["traffic"] is None
+    assert line["unit"].startswith(flags[1].upper())
