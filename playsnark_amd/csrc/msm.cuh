@@ -124,8 +124,12 @@ PS_INL u32 limb_sel8(const u32* k, int i) {  // k[i] (0 beyond the end) without 
     return v;
 }
 constexpr int DIGITS_THREADS = 1024;
-constexpr int DIGITS_PER_THREAD = 16;
-constexpr int DIGITS_CHUNK = DIGITS_THREADS * DIGITS_PER_THREAD;  // 16384 scalars per workgroup
+#ifndef PS_DIGITS_PER_THREAD
+#define PS_DIGITS_PER_THREAD 8  // 8192 scalars per workgroup: two partition workgroups per CU (64 KB of LDS each).  With 16 (one
+                               // workgroup per CU, runs of 16 entries per bin) k_sort_partition took 108 instead of 93 us at 2^20
+#endif
+constexpr int DIGITS_PER_THREAD = PS_DIGITS_PER_THREAD;
+constexpr int DIGITS_CHUNK = DIGITS_THREADS * DIGITS_PER_THREAD;  // 8192 scalars per workgroup
 constexpr int DIGITS_BINS = 2048;
 
 __device__ inline u32 wave_incl_scan(u32 v);
