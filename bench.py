@@ -79,6 +79,91 @@ def witness_values(n: int, seed: int):
     return w
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Verification that needs neither the oracle nor a second GPU pass: the synthetic points are P_i = a_i * G with the
+# a_i known on the host, so  sum_i k_i P_i = (sum_i a_i k_i mod r) * G  -- the reference's own test method
+# (groth16_test.go:41-106 recomputes discrete logs from the retained toxic waste).  One fixed-base multiplication in
+# plain Python integers (affine chord-and-tangent over Fp / Fp2, public BLS12-381 constants), independent of both the
+# product and oracle/.  Works for any rank count: every rank checks its own partial sum, rank 0 the folded one.
+# ---------------------------------------------------------------------------------------------------------
+P_MOD = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+G1_GEN = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+G2_GEN = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+           0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+          (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+           0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
+
+
+class _Fp:
+    zero, one = 0, 1
+    add = staticmethod(lambda a, b: (a + b) % P_MOD)
+    sub = staticmethod(lambda a, b: (a - b) % P_MOD)
+    mul = staticmethod(lambda a, b: a * b % P_MOD)
+    inv = staticmethod(lambda a: pow(a, -1, P_MOD))
+    to_b = staticmethod(lambda a: a.to_bytes(48, "big"))
+
+
+class _Fp2:  # Fp[u] / (u^2 + 1), elements (c0, c1); wire order c1 || c0 (the ZCash / kyber serialisation)
+    zero, one = (0, 0), (1, 0)
+    add = staticmethod(lambda a, b: ((a[0] + b[0]) % P_MOD, (a[1] + b[1]) % P_MOD))
+    sub = staticmethod(lambda a, b: ((a[0] - b[0]) % P_MOD, (a[1] - b[1]) % P_MOD))
+    mul = staticmethod(lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P_MOD, (a[0] * b[1] + a[1] * b[0]) % P_MOD))
+    to_b = staticmethod(lambda a: a[1].to_bytes(48, "big") + a[0].to_bytes(48, "big"))
+
+    @staticmethod
+    def inv(a):
+        d = pow(a[0] * a[0] + a[1] * a[1], -1, P_MOD)
+        return (a[0] * d % P_MOD, -a[1] * d % P_MOD)
+
+
+def fixed_base_mul_bytes(group: str, s: int) -> bytes:
+    """s * G as the library serialises a point (affine big-endian x || y; the identity is 0x40 followed by zeros)."""
+    F, gen = (_Fp, G1_GEN) if group == "g1" else (_Fp2, G2_GEN)
+    size = 96 if group == "g1" else 192
+
+    def add(p, q):
+        if p is None:
+            return q
+        if q is None:
+            return p
+        (x1, y1), (x2, y2) = p, q
+        if x1 == x2:
+            if F.add(y1, y2) == F.zero:
+                return None
+            three = F.add(F.add(F.one, F.one), F.one)
+            lam = F.mul(F.mul(three, F.mul(x1, x1)), F.inv(F.add(y1, y1)))
+        else:
+            lam = F.mul(F.sub(y2, y1), F.inv(F.sub(x2, x1)))
+        x3 = F.sub(F.sub(F.mul(lam, lam), x1), x2)
+        return (x3, F.sub(F.mul(lam, F.sub(x1, x3)), y1))
+
+    acc, base = None, gen
+    s %= R_MOD
+    while s:
+        if s & 1:
+            acc = add(acc, base)
+        base = add(base, base)
+        s >>= 1
+    if acc is None:
+        return bytes([0x40]) + bytes(size - 1)
+    return F.to_b(acc[0]) + F.to_b(acc[1])
+
+
+def dlog_of_sum(a_be32: bytes, scalars) -> int:
+    """sum_i a_i k_i mod r; `scalars` is the big-endian byte string the GPU got, or the list of int64 witness values."""
+    n = len(a_be32) // 32
+    fb = int.from_bytes
+    if isinstance(scalars, (bytes, bytearray)):
+        ks = (fb(scalars[32 * i:32 * i + 32], "big") for i in range(n))
+    else:
+        ks = iter(scalars)
+    acc = 0
+    for i, k in zip(range(n), ks):
+        acc += fb(a_be32[32 * i:32 * i + 32], "big") * k  # (a negative witness value v stands for r - |v|: the same residue)
+    return acc % R_MOD
+
+
 def cpu_baseline(group: str, points_raw: bytes, scalars_be32: bytes, n: int, gpu_result: bytes):
     """Oracle CPU Pippenger (plain-C port, pthreads over windows) on the SAME points and scalars the GPU
     summed (a bounded sample of them when the workload is larger than 2^20).  Returns (block, verified)."""
@@ -341,7 +426,8 @@ def main():
     # synthetic inputs, resident in HBM before the timed region:
     #   points  P_i = a_i * G from the device fixed-base kernel (a_i uniform, seeded per rank)
     #   scalars uniform in [0, r)
-    a = api.Poly.upload(ctx, uniform_scalars_be32(n, SEED + 1000 + rank).tobytes())
+    host_a = uniform_scalars_be32(n, SEED + 1000 + rank).tobytes()
+    a = api.Poly.upload(ctx, host_a)
     gid = api.G1 if g == "g1" else api.G2
     points = api.Points.from_scalars(ctx, gid, a)
     if not args.no_table and not args.window:  # the CRS is fixed across proofs: its window table is built once, like the upload
@@ -405,6 +491,17 @@ def main():
     stage_ms = {k: v / max(args.steps, 1) for k, v in stage_ms.items()}
     ctx.set_timing(False)
 
+    # ---- verification by discrete logarithm, for ANY rank count (outside the timed region): every rank checks the partial
+    # sum of its own shard, rank 0 the folded result of the timed run ----
+    s_rank = dlog_of_sum(host_a, host_scalars if host_scalars is not None else host_values)
+    api.msm_launch(ctx, points, scalars)
+    my_partial = api.msm_finish(ctx, gid)  # this rank's sum before any exchange
+    mine = (s_rank, bool(my_partial == fixed_base_mul_bytes(g, s_rank)))
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank == 0:
         total_muls = float(n_total) * args.steps
         value = total_muls / elapsed
@@ -428,7 +525,18 @@ def main():
         exchange = ""
         if world > 1 and backend_used != "nccl":  # a number whose exchange did NOT run over RCCL must say so where it is read
             exchange = " (gloo exchange%s)" % (": RCCL init failed" if "failed" in str(backend_used) else "")
-        mad_peak = ctx.microbench_mad()  # ~1 ms, outside the timed region: the integer roofline measured in this run
+        # ~1 ms, outside the timed region, on the printing rank only: the integer roofline measured in this run.  A failed or
+        # empty measurement must not cost the line its headline number: fall back to round 1's figure and say so.
+        mad_peak_source = "ps_microbench_mad in this run (v_mad_u64_u32, 8 chains per lane, 2 waves per SIMD, all CUs)"
+        try:
+            mad_peak = float(ctx.microbench_mad())
+        except Exception as e:  # noqa: BLE001
+            mad_peak = 0.0
+            mad_peak_source = "round-1 microbenchmark (ps_microbench_mad failed in this run: %s)" % type(e).__name__
+        if not mad_peak > 0.0:
+            mad_peak = MAD_PEAK_ROUND1
+            if "failed" not in mad_peak_source:
+                mad_peak_source = "round-1 microbenchmark (ps_microbench_mad measured no interval in this run)"
         line = {
             "metric": "%s scalar-muls/s (Pippenger MSM, %s)%s" % (
                 g.upper(), ("2^%d pts total" % args.total_log2n) if strong else ("2^%d pts per GPU" % args.log2n), exchange),
@@ -483,7 +591,7 @@ def main():
                 "int_alu": {
                     "mads_per_launch": info["entries"] * MADS_PER_MIXED_ADD[g],
                     "peak_mads_per_s": mad_peak,
-                    "peak_source": "ps_microbench_mad in this run (v_mad_u64_u32, 8 chains per lane, 2 waves per SIMD, all CUs)",
+                    "peak_source": mad_peak_source,
                     "peak_mads_per_s_round1": MAD_PEAK_ROUND1,
                     "frac": info["entries"] * MADS_PER_MIXED_ADD[g] / (acc_ms * 1e-3) / mad_peak if acc_ms > 0 else 0.0,
                     "frac_one_at_a_time": info["entries"] * MADS_PER_MIXED_ADD[g] / (single_acc_ms * 1e-3) / mad_peak
@@ -498,6 +606,15 @@ def main():
             "result_affine_hex": result.hex()[:32] + "...",
             "verified": None,
         }
+        ranks_ok = [bool(ok) for _s, ok in per_rank]
+        folded_ok = bool(result == fixed_base_mul_bytes(g, sum(sr for sr, _ok in per_rank) % R_MOD))
+        line["verified_dlog"] = {
+            "ranks": ranks_ok, "folded": folded_ok,
+            "note": "P_i = a_i G with the a_i known on the host: each rank's partial sum == (sum a_i k_i mod r) G over its shard, and the "
+                    "folded result of the timed run == (sum over all ranks) G; plain-integer fixed-base multiplication in bench.py "
+                    "(groth16_test.go:41-106's method), no oracle, no second GPU pass",
+        }
+        line["verified"] = all(ranks_ok) and folded_ok
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 of the one-GPU run only
             ns = min(n, 1 << args.cpu_sample_log2)
             sample_pts, sample_sc = points.slice(0, ns), scalars.slice(0, ns)
@@ -506,8 +623,8 @@ def main():
             line["cpu_baseline"] = block
             line["cpu_baseline_reference_algorithm"] = reference_algorithm_baseline(sample_pts.download(0, 1 << 12),
                                                                                    sample_sc.download_bytes(0, 1 << 12)) if ns >= 1 << 12 and g == "g1" else None
-            line["verified"] = verified
-            line["verified_note"] = "GPU sum == oracle CPU Pippenger on the same %d points and scalars (affine bytes)" % ns
+            line["verified"] = bool(verified) and line["verified"]
+            line["verified_note"] = "GPU sum == oracle CPU Pippenger on the same %d points and scalars (affine bytes), and verified_dlog" % ns
         if not args.no_extras and world == 1 and not strong:
             line["extras"] = extras(api, ctx, args, mad_peak)
         print(json.dumps(line))
