@@ -149,13 +149,38 @@ struct Storage {  // shared device allocation behind slices
     std::atomic<void*> table{nullptr};
     int table_c = 0, table_W = 0;
     size_t table_stride = 0;
-    bool table_declined = false;  // a prover found no room for it (points_ensure_table): not asked again
+    // A prover found no room for the table (points_ensure_table).  The mark is not for ever: it records what the asking context
+    // had to offer -- its budget and the free device memory -- and a later request that has more of either asks again (a
+    // key is shared between contexts: one with a small ps_ctx_set_table_budget must not decide for all).
+    bool table_declined = false;
+    long long declined_budget = 0;  // negative: automatic
+    size_t declined_free = 0;
     size_t count = 0;  // elements in the allocation (point arrays)
+    // Window tables of index ranges of the allocation (ViewTable below): an index-range shard of a key whose table was built
+    // for the WHOLE array would reduce that table's 2^(c-1) buckets for an eighth of the points; the first sum over such
+    // a view builds a table of the view's own (window chosen for ITS length) under `mu`.  Slots are published with release
+    // and never change afterwards (until ps_points_precompute(p, -1) / the last handle goes), readers scan them without the lock.
+    static constexpr int VIEW_SLOTS = 64;
+    std::atomic<struct ViewTable*> vtab[VIEW_SLOTS] = {};
 };
+struct ViewTable {
+    size_t first, n;  // the index range [first, first + n) of the allocation
+    int c, W;         // window bits, rows
+    void* table;      // W rows of n points (row stride n); nullptr: no room when it was asked for (declined_* as for the whole table)
+    long long declined_budget;
+    size_t declined_free;
+};
+static void storage_free_view_tables(Storage* s) {
+    for (auto& slot : s->vtab) {
+        ViewTable* v = slot.exchange(nullptr);
+        if (v) { if (v->table) (void)hipFree(v->table); delete v; }
+    }
+}
 static void storage_unref(Storage* s) {
     if (s && s->refs.fetch_sub(1) == 1) {
         if (s->ready) (void)hipEventDestroy(s->ready);
         if (s->table.load()) (void)hipFree(s->table.load());
+        storage_free_view_tables(s);
         if (s->p) (void)hipFree(s->p);
         delete s;
     }
@@ -611,13 +636,12 @@ static int table_window_for(size_t n) {
     return best;
 }
 template <class F>
-static int build_table(ps_ctx* c, Storage* st, void* table, int group, int wbits, int W) {
+static int build_table(ps_ctx* c, const void* points, size_t n, void* table, int group, int wbits, int W) {
     typedef typename KernelField<F>::type KF;
     constexpr unsigned LN = FieldTraits<KF>::LANES;
-    const size_t n = st->count;
     const u32 rb = (u32)table_row_bytes(group);
     char* tab = (char*)table;
-    hipLaunchKernelGGL(k_table_row0<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<F>*)st->p, tab, rb, (u32)n);
+    hipLaunchKernelGGL(k_table_row0<F>, dim3(nblocks(n)), dim3(256), 0, c->stream, (const Affine<F>*)points, tab, rb, (u32)n);
     if (W > 1) {
         int rc = c->affine_tmp.ensure(batch_affine_tmp_bytes(n, sizeof(Xyzz<F>)));
         if (rc) return rc;
@@ -640,6 +664,21 @@ static bool table_fits(const ps_ctx* c, size_t bytes) {
     const size_t reserve = std::max<size_t>(total_b / 16, (size_t)2 << 30);
     return bytes + reserve <= free_b;
 }
+// What a context had to offer when a table was declined, and whether a later request has more: a larger budget, or a
+// quarter more free device memory (hipMemGetInfo is only asked on this path -- a key whose table was declined).
+static void decline_record(const ps_ctx* c, long long* budget, size_t* free_bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    *budget = c->table_budget;
+    *free_bytes = free_b;
+}
+static bool decline_outdated(const ps_ctx* c, long long budget, size_t free_bytes) {
+    if (budget >= 0 && (c->table_budget < 0 || c->table_budget > budget)) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return free_b > free_bytes + free_bytes / 4;
+}
+
 // The table of the allocation behind `p` for `window_bits` (0 = automatic), built once whoever asks first.
 // optional: a prover's request -- no room (budget, free memory, or hipMalloc failing) is not an error: the array is marked
 // and the sums over it take the plain plan.  Returns with the table complete in memory (the context stream is waited for).
@@ -655,14 +694,17 @@ static int points_ensure_table(ps_ctx* c, const ps_points* p, int window_bits, b
     if (st->table.load(std::memory_order_acquire) && st->table_c == wbits) return PS_OK;
     std::lock_guard<std::mutex> lock(st->mu);
     if (st->table.load(std::memory_order_acquire) && st->table_c == wbits) return PS_OK;  // another context built it meanwhile
-    if (optional && (st->table_declined || st->table.load())) return PS_OK;  // asked before / the caller's own table stays
+    if (optional && st->table.load()) return PS_OK;  // the caller's own table stays
+    if (optional && st->table_declined && !decline_outdated(c, st->declined_budget, st->declined_free)) return PS_OK;  // asked before, nothing has changed
     const int W = 255 / wbits + 1;
     const size_t bytes = table_row_bytes(p->group) * n * (size_t)W;
     const size_t work = batch_affine_tmp_bytes(n, p->group == PS_G1 ? sizeof(Xyzz<Fp>) : sizeof(Xyzz<Fp2>));
     if (optional && !table_fits(c, bytes + (c->affine_tmp.cap >= work ? 0 : work))) {
+        decline_record(c, &st->declined_budget, &st->declined_free);
         st->table_declined = true;
         return PS_OK;
     }
+    st->table_declined = false;
     if (storage_wait_ready(st, c->stream)) return fail(PS_ERR_HIP, "ps_points_precompute: event wait failed");
     if (void* old = st->table.load()) {  // another window size: sums of THIS process that may still read the old table are waited for
         HIP_TRY(hipDeviceSynchronize());
@@ -676,12 +718,13 @@ static int points_ensure_table(ps_ctx* c, const ps_points* p, int window_bits, b
         (void)hipGetLastError();
         rc = fail(PS_ERR_HIP, std::string("hipMalloc window table: ") + hipGetErrorString(e));
     } else {
-        rc = p->group == PS_G1 ? build_table<Fp>(c, st, tab, PS_G1, wbits, W) : build_table<Fp2>(c, st, tab, PS_G2, wbits, W);
+        rc = p->group == PS_G1 ? build_table<Fp>(c, st->p, n, tab, PS_G1, wbits, W) : build_table<Fp2>(c, st->p, n, tab, PS_G2, wbits, W);
         if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(PS_ERR_HIP, "ps_points_precompute: building the table failed");
         if (rc) (void)hipFree(tab);
     }
     if (rc) {
         if (!optional) return rc;
+        decline_record(c, &st->declined_budget, &st->declined_free);
         st->table_declined = true;  // no room after all (e.g. the staging buffer): the plain plan needs no extra memory
         g_last_error.clear();
         return PS_OK;
@@ -692,6 +735,70 @@ static int points_ensure_table(ps_ctx* c, const ps_points* p, int window_bits, b
     st->table.store(tab, std::memory_order_release);
     return PS_OK;
 }
+// ---- window tables of index ranges (ViewTable) ----
+static const ViewTable* view_table_find(const Storage* st, size_t first, size_t n, int wbits /* 0: any */) {
+    for (const auto& slot : st->vtab) {
+        const ViewTable* v = slot.load(std::memory_order_acquire);
+        if (!v) break;  // slots fill in order
+        if (v->first == first && v->n == n && (wbits == 0 || v->c == wbits)) return v;
+    }
+    return nullptr;
+}
+// Table of the index range behind the view `p` (p->first, p->n) for its own length, built on first use.  Always optional:
+// no room (budget, free memory, no free slot) leaves the view on whatever plan it had.  Returns the table or nullptr.
+static const ViewTable* view_table_ensure(ps_ctx* c, const ps_points* p) {
+    Storage* st = p->st;
+    const size_t n = p->n;
+    const int wbits = table_window_for(n);
+    const ViewTable* have = view_table_find(st, p->first, n, 0);
+    if (have && (have->table || !decline_outdated(c, have->declined_budget, have->declined_free))) return have->table ? have : nullptr;
+    std::lock_guard<std::mutex> lock(st->mu);
+    have = view_table_find(st, p->first, n, 0);
+    int slot = -1;
+    for (int i = 0; i < Storage::VIEW_SLOTS; i++) {
+        ViewTable* v = st->vtab[i].load(std::memory_order_acquire);
+        if (!v) { slot = i; break; }
+        if (v == have) {
+            if (v->table) return v;  // another context built it meanwhile
+            if (!decline_outdated(c, v->declined_budget, v->declined_free)) return nullptr;
+        }
+    }
+    const int W = 255 / wbits + 1;
+    const size_t bytes = table_row_bytes(p->group) * n * (size_t)W;
+    const size_t work = batch_affine_tmp_bytes(n, p->group == PS_G1 ? sizeof(Xyzz<Fp>) : sizeof(Xyzz<Fp2>));
+    ViewTable* decl = const_cast<ViewTable*>(have);  // a declined record is refreshed in place (only its decline fields, under mu)
+    auto declined = [&]() -> const ViewTable* {
+        if (decl) { decline_record(c, &decl->declined_budget, &decl->declined_free); return nullptr; }
+        if (slot < 0) return nullptr;
+        ViewTable* v = new ViewTable{p->first, n, wbits, W, nullptr, 0, 0};
+        decline_record(c, &v->declined_budget, &v->declined_free);
+        st->vtab[slot].store(v, std::memory_order_release);
+        return nullptr;
+    };
+    if (slot < 0 && !decl) return nullptr;  // every slot taken by other ranges
+    if (!table_fits(c, bytes + (c->affine_tmp.cap >= work ? 0 : work))) return declined();
+    if (storage_wait_ready(st, c->stream)) return nullptr;
+    void* tab = nullptr;
+    if (hipMalloc(&tab, bytes) != hipSuccess) { (void)hipGetLastError(); return declined(); }
+    const void* base = points_ptr(p);
+    int rc = p->group == PS_G1 ? build_table<Fp>(c, base, n, tab, PS_G1, wbits, W) : build_table<Fp2>(c, base, n, tab, PS_G2, wbits, W);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || rc) {
+        (void)hipFree(tab);
+        g_last_error.clear();
+        return declined();
+    }
+    if (decl) {
+        // the declined record becomes the table: readers that saw table == nullptr took another plan; publish the pointer last
+        decl->c = wbits; decl->W = W;
+        std::atomic_thread_fence(std::memory_order_release);
+        reinterpret_cast<std::atomic<void*>&>(decl->table).store(tab, std::memory_order_release);
+        return decl;
+    }
+    ViewTable* v = new ViewTable{p->first, n, wbits, W, tab, 0, 0};
+    st->vtab[slot].store(v, std::memory_order_release);
+    return v;
+}
+
 extern "C" int ps_points_precompute(ps_ctx* c, ps_points* p, int window_bits) {
     if (!c || !p) return fail(PS_ERR_ARG, "ps_points_precompute: NULL argument");
     if (window_bits == -1) {  // release
@@ -699,9 +806,10 @@ extern "C" int ps_points_precompute(ps_ctx* c, ps_points* p, int window_bits) {
         std::lock_guard<std::mutex> lock(st0->mu);
         void* old = st0->table.load();
         st0->table_declined = false;
-        if (!old) return PS_OK;
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipDeviceSynchronize());
+        storage_free_view_tables(st0);
+        if (!old) return PS_OK;
         st0->table.store(nullptr, std::memory_order_release);
         (void)hipFree(old);
         st0->table_c = st0->table_W = 0;
@@ -954,6 +1062,28 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     return PS_OK;
 }
 
+// The window table a sum over (pts, n) with c-bit windows and W digits reads: the table of the whole allocation (rows of
+// table_stride points, the view starts at its own offset) or the table of exactly this index range (ViewTable).
+struct TableRef { const char* base; u64 stride; };
+static bool table_ref(const ps_points* pts, size_t n, int wbits, int W, TableRef* out) {
+    const Storage* st = pts->st;
+    const size_t rb = table_row_bytes(pts->group);
+    if (const void* t = st->table.load(std::memory_order_acquire)) {
+        if (st->table_c == wbits && W <= st->table_W) {
+            *out = TableRef{(const char*)t + pts->first * rb, (u64)st->table_stride};
+            return true;
+        }
+    }
+    if (const ViewTable* v = view_table_find(st, pts->first, n, wbits)) {
+        const void* t = reinterpret_cast<const std::atomic<void*>&>(v->table).load(std::memory_order_acquire);
+        if (t && W <= v->W) {
+            *out = TableRef{(const char*)t, (u64)v->n};
+            return true;
+        }
+    }
+    return false;
+}
+
 // Window sums of one point array over the sorted entries of `c`, copied to pinned slot `slot` of `c`.
 // The work buffers and the stream are those of `wc` (c itself, or c->aux when ps_msm_multi
 // alternates two workspaces so that the latency-bound tail of one sum -- fix-up and reduction, ~1.3 ms
@@ -979,9 +1109,11 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const u32 per_role = rp.m * (u32)pl.sets, nres = rp.njobs * (u32)pl.sets;
     const bool tab = pl.table;
     const u32 pstride = tab ? (u32)table_row_bytes(pts->group) : (u32)sizeof(Affine<F>);
-    const char* src = tab ? (const char*)pts->st->table.load(std::memory_order_acquire) + pts->first * (size_t)pstride : (const char*)points_ptr(pts);
+    TableRef tref{};
+    if (tab && !table_ref(pts, n, pl.c, pl.W, &tref)) return fail(PS_ERR_ARG, "msm: internal: the plan names a window table the array does not carry");
+    const char* src = tab ? tref.base : (const char*)points_ptr(pts);
     const u32 idx_mask = tab ? (1u << ENTRY_W_SHIFT) - 1u : 0x7fffffffu;
-    const u64 w_stride = tab ? (u64)pts->st->table_stride : 0ull;
+    const u64 w_stride = tab ? tref.stride : 0ull;
     int rc;
     if ((rc = wc->buckets.ensure(sizeof(Xyzz<F>) * G))) return rc;
     if ((rc = wc->parts.ensure(sizeof(Xyzz<F>) * 2 * (size_t)nthreads_acc))) return rc;
@@ -1177,12 +1309,39 @@ static void msm_plan_tail(MsmPlan& pl, size_t n, int group, int forced, bool bus
 #ifndef PS_TABLE_COST_MARGIN
 #define PS_TABLE_COST_MARGIN 0.9  // the plain plan must be this much cheaper in the model to replace a table that exists
 #endif
-static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t k, size_t n, int max_bits, MsmPlan* out) {
+#ifndef PS_VIEW_TABLE_MIN_POINTS
+#define PS_VIEW_TABLE_MIN_POINTS 1024  // index-range views shorter than this keep the plan of the whole array (latency-bound anyway)
+#endif
+static inline double table_plan_cost(size_t n, int max_bits, int wbits) {
+    return (double)n * (max_bits / wbits + 1) * 10.0 + (double)(1u << (wbits - 1)) * 42.0;
+}
+static int msm_plan_checked(ps_ctx* c, const ps_points* const* pts, size_t k, size_t n, int max_bits, MsmPlan* out) {
     // The window-table plan needs every array of the call to carry a table for the same window size
     bool tab = k > 0;
     for (size_t i = 0; i < k && tab; i++)
         tab = table_usable(c, pts[i], n, max_bits) && pts[i]->st->table_c == pts[0]->st->table_c;
-    MsmPlan pl = tab ? msm_plan_table(n, max_bits, pts[0]->st->table_c) : msm_plan(n, max_bits, c->forced_c);
+    int tab_c = tab ? pts[0]->st->table_c : 0;
+    // Index-range views of arrays that carry a table for the WHOLE allocation (the shares of a sharded prover: an eighth of
+    // a 2^20-point key over its 20-bit table reduces 2^19 buckets for 2^17 points -- 9.2 ms per share where the work is
+    // ~2 ms, tools/g16_shares.py): a table of the view's own, window chosen for ITS length, built on first use under the
+    // table budget (view_table_ensure).  Only where the model says it pays, and only for arrays whose owner asked for tables.
+    if (k > 0 && !c->forced_c && c->use_tables && n >= PS_VIEW_TABLE_MIN_POINTS && n < (1ull << ENTRY_W_SHIFT)) {
+        const int vc = table_window_for(n);
+        bool views = true;
+        for (size_t i = 0; i < k && views; i++) {
+            const Storage* st = pts[i]->st;
+            views = n < st->count && (st->table.load(std::memory_order_acquire) || view_table_find(st, pts[i]->first, n, 0));
+        }
+        if (views && (!tab || table_plan_cost(n, max_bits, vc) < PS_TABLE_COST_MARGIN * table_plan_cost(n, max_bits, tab_c))) {
+            bool all = true;
+            for (size_t i = 0; i < k && all; i++) {
+                const ViewTable* v = view_table_ensure(c, pts[i]);
+                all = v && v->c == vc;
+            }
+            if (all) { tab = true; tab_c = vc; }
+        }
+    }
+    MsmPlan pl = tab ? msm_plan_table(n, max_bits, tab_c) : msm_plan(n, max_bits, c->forced_c);
     if (tab && k == 1) {
         // Short scalars (an int64 witness over a table built for 20-bit windows: 4 windows, but 2^19 buckets to reduce) are
         // cheaper on the plain plan with its small windows -- same cost model as msm_plan: 10 field products per bucket
@@ -1207,6 +1366,9 @@ static int msm_plan_checked(const ps_ctx* c, const ps_points* const* pts, size_t
     return PS_OK;
 }
 
+#ifndef PS_MULTI_CHAIN_MIN_ENTRIES
+#define PS_MULTI_CHAIN_MIN_ENTRIES (1ull << 40)  // the point passes of ONE multi-sum: never chained (msm_multi_points)
+#endif
 #ifndef PS_CHAIN_MIN_ENTRIES
 #define PS_CHAIN_MIN_ENTRIES (1ull << 21)  // sums with fewer digits than this are not chained behind the previous accumulation
 #endif
@@ -1306,7 +1468,12 @@ static int msm_multi_points(ps_ctx* c, ps_ctx* const* ring, const ps_points* con
         if (!c->ev_multi[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_multi[i], hipEventDisableTiming));
         if (!c->ev_acc[i]) HIP_TRY(hipEventCreateWithFlags(&c->ev_acc[i], hipEventDisableTiming));
         ps_ctx* wc = ring[i % PS_MULTI_RING];
-        const bool chained = (u64)pl.W * sc->n >= PS_CHAIN_MIN_ENTRIES;  // short sums run side by side (msm_launch_impl)
+        // The accumulations of a multi-sum are NOT chained behind each other (round 4; PS_MULTI_CHAIN_MIN_ENTRIES): all of them
+        // are enqueued at once, on rotating workspaces, and when they share the chip the workgroups of the next one fill the
+        // SIMDs the previous one's last, ragged round leaves idle.  A/B on one box, PHGR13Prove at 2^20 constraints (seven
+        // sums over one sort): 30.5-31.8 ms chained, 27.7-28.7 unchained.  (Independent sums in flight, msm_launch_impl, keep
+        // the chain: 2^20-point G1 sums 2.97 ms per step chained, 3.03-3.08 unchained.)
+        const bool chained = (u64)pl.W * sc->n >= PS_MULTI_CHAIN_MIN_ENTRIES;
         hipEvent_t wait = !chained ? nullptr : i ? c->ev_acc[i - 1] : first_wait;
         int rc = pts[i]->group == PS_G1 ? msm_points_t<Fp>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i])
                                         : msm_points_t<Fp2>(w0, wc, pts[i], sc->n, pl, false, (int)i, wait, c->ev_acc[i]);

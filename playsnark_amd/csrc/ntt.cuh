@@ -78,6 +78,12 @@ struct NttFuse {
     int logs = 0;                 // UPPER_HALF / COMBINE: node size
     u64 cnt = 0;                  // *_PAD / *TAKE: element count
     u64 top = 0;                  // REV_PAD / REV_TAKE: index that maps to 0
+    // A batch of two transforms in one buffer (the two interpolations of Groth16's route, quotient.cuh): element index =
+    // member << batch_log | i.  SCALE_PAD reads member 1 from ld_src2 (cnt and the factors apply per member); TAKE writes
+    // member m's first cnt values to st_dst[m << st_member_log | i].  The defaults describe a single transform.
+    int batch_log = 63;
+    const Fr* ld_src2 = nullptr;
+    int st_member_log = 0;
 };
 
 // __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Four 256-thread workgroups
@@ -89,40 +95,64 @@ __device__ unsigned long long* ntt_trace = nullptr;  // 4 timestamps (s_memtime,
 #else
 #define PS_NTT_STAMP(i) do { } while (0)
 #endif
+// ---- pieces of a pass, shared by k_ntt_pass and k_ntt_mid ----
+struct NttTile {  // geometry of one workgroup's tile: 2^k rows x 2^logCols columns, first column q0
+    int p, logD, k, logCols;
+    u64 q0;
+};
+// HBM index of tile element e (the order that keeps consecutive e consecutive in HBM whichever way the pass strides), and
+// its slot t * COLS + col in the LDS tile
+PS_INL void ntt_tile_map(const NttTile& g, u32 e, u64& addr, u32& slot) {
+    const u32 COLS = 1u << g.logCols, rows = 1u << g.k;
+    const u64 Dm1 = (1ull << g.logD) - 1;
+    u32 t, col;
+    if (g.logD >= g.logCols) { t = e >> g.logCols; col = e & (COLS - 1); }
+    else { u32 lo = e & (u32)Dm1; t = (e >> g.logD) & (rows - 1); u32 hl = e >> (g.logD + g.k); col = (hl << g.logD) | lo; }
+    const u64 q = g.q0 + col;
+    addr = ((q >> g.logD) << (g.logD + g.k)) + ((u64)t << g.logD) + (q & Dm1);
+    slot = t * COLS + col;
+}
+PS_INL Fr ntt_load_fused(const Fr* __restrict__ data, u64 addr, const NttFuse& fz) {
+    if (fz.ld == NTT_LD_PLAIN) return data[addr];
+    if (fz.ld == NTT_LD_UPPER_HALF) {
+        const u64 half = 1ull << (fz.logs - 1);
+        return (addr & (2 * half - 1)) < half ? fz.ld_src[addr + half] : fr_zero();
+    }
+    if (fz.ld == NTT_LD_SCALE_PAD) {
+        const u64 i = addr & ((1ull << fz.batch_log) - 1);
+        const Fr* src = (addr >> fz.batch_log) ? fz.ld_src2 : fz.ld_src;
+        return i < fz.cnt ? fr_mul(src[i], fz.ld_aux[i]) : fr_zero();
+    }
+    if (fz.ld == NTT_LD_PAD) return addr < fz.cnt ? fz.ld_src[addr] : fr_zero();
+    return addr < fz.cnt ? fz.ld_src[fz.top - addr] : fr_zero();
+}
+PS_INL void ntt_store_fused(Fr* __restrict__ data, u64 addr, const Fr& v, const NttFuse& fz) {
+    if (fz.st == NTT_ST_PLAIN) {
+        data[addr] = v;
+    } else if (fz.st == NTT_ST_MUL) {
+        data[addr] = fr_mul(v, fz.st_aux[addr & fz.aux_mask]);
+    } else if (fz.st == NTT_ST_COMBINE) {
+        const u64 half = 1ull << (fz.logs - 1);
+        fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
+    } else if (fz.st == NTT_ST_TAKE) {
+        const u64 i = addr & ((1ull << fz.batch_log) - 1);
+        if (i < fz.cnt) fz.st_dst[((addr >> fz.batch_log) << fz.st_member_log) + i] = v;
+    } else if (addr < fz.cnt) {
+        fz.st_dst[fz.top - addr] = v;
+    }
+}
+
+// The k butterfly stages of a pass on the LDS tile (ends with a barrier).
+// Two butterfly stages per LDS round trip where possible: a thread takes the four rows that differ
+// in row bits m and m+1, so loads, stores, index arithmetic and barriers are halved.  Forward
+// (Cooley-Tukey) walks m = k-1 .. 0, inverse (Gentleman-Sande) m = 0 .. k-1.
 template <bool INV>
-__global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
-                                                  const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
-    extern __shared__ __align__(16) unsigned char ntt_smem[];
-    Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
-    PS_NTT_STAMP(0);
+__device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, const NttTile& g, const Fr* __restrict__ tw, int log_tab) {
+    const int p = g.p, logD = g.logD, k = g.k, logCols = g.logCols;
     const u32 COLS = 1u << logCols, rows = 1u << k;
-    const u32 tile_elems = rows << logCols;
-    const u64 q0 = (u64)blockIdx.x << logCols;
+    const u64 q0 = g.q0;
     const u64 Dm1 = (1ull << logD) - 1;
     const u64 smask = (1ull << p) - 1;
-    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
-        u32 t, col;
-        if (logD >= logCols) { t = e >> logCols; col = e & (COLS - 1); }
-        else { u32 lo = e & (u32)Dm1; t = (e >> logD) & (rows - 1); u32 hl = e >> (logD + k); col = (hl << logD) | lo; }
-        u64 q = q0 + col;
-        u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
-        Fr v;
-        if (fz.ld == NTT_LD_PLAIN) {
-            v = data[addr];
-        } else if (fz.ld == NTT_LD_UPPER_HALF) {
-            const u64 half = 1ull << (fz.logs - 1);
-            v = (addr & (2 * half - 1)) < half ? fz.ld_src[addr + half] : fr_zero();
-        } else if (fz.ld == NTT_LD_SCALE_PAD) {
-            v = addr < fz.cnt ? fr_mul(fz.ld_src[addr], fz.ld_aux[addr]) : fr_zero();
-        } else if (fz.ld == NTT_LD_PAD) {
-            v = addr < fz.cnt ? fz.ld_src[addr] : fr_zero();
-        } else {
-            v = addr < fz.cnt ? fz.ld_src[fz.top - addr] : fr_zero();
-        }
-        tile[t * COLS + col] = v;
-    }
-    __syncthreads();
-    PS_NTT_STAMP(1);
     // global index of element (row t, column col) of this tile, and the twiddle of the butterfly block
     // that holds global index i at a stage with half-distance 2^logh (returns false when w = 1)
     auto gidx = [&](u32 t, u32 col) -> u64 {
@@ -136,9 +166,6 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         w = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
         return true;
     };
-    // Two butterfly stages per LDS round trip where possible: a thread takes the four rows that differ
-    // in row bits m and m+1, so loads, stores, index arithmetic and barriers are halved.  Forward
-    // (Cooley-Tukey) walks m = k-1 .. 0, inverse (Gentleman-Sande) m = 0 .. k-1.
     const u32 nbf = (rows >> 1) << logCols, nq = (rows >> 2) << logCols;
     int done_st = 0;
     while (done_st < k) {
@@ -205,6 +232,25 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         }
         __syncthreads();
     }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+                                                  const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
+    extern __shared__ __align__(16) unsigned char ntt_smem[];
+    Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
+    PS_NTT_STAMP(0);
+    const NttTile g{p, logD, k, logCols, (u64)blockIdx.x << logCols};
+    const u32 tile_elems = 1u << (k + logCols);
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u64 addr;
+        u32 slot;
+        ntt_tile_map(g, e, addr, slot);
+        tile[slot] = ntt_load_fused(data, addr, fz);
+    }
+    __syncthreads();
+    PS_NTT_STAMP(1);
+    ntt_tile_stages<INV>(tile, g, tw, log_tab);
     // The inverse doubles along the all-sums path (a product pulls a value back under 2r, a sum does not);
     // 2^16 r still fits the lazy limbs with room to spare (top limb < 2^20), so ntt_run asks for the
     // scaling 2^-scale_log only in the last pass of a transform, or earlier for very long ones.
@@ -215,25 +261,59 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[scale_log][j];
     }
     for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
-        u32 t, col;
-        if (logD >= logCols) { t = e >> logCols; col = e & (COLS - 1); }
-        else { u32 lo = e & (u32)Dm1; t = (e >> logD) & (rows - 1); u32 hl = e >> (logD + k); col = (hl << logD) | lo; }
-        u64 q = q0 + col;
-        u64 addr = ((q >> logD) << (logD + k)) + ((u64)t << logD) + (q & Dm1);
-        Fr v = tile[t * COLS + col];
+        u64 addr;
+        u32 slot;
+        ntt_tile_map(g, e, addr, slot);
+        Fr v = tile[slot];
         if (INV && scale_log) v = fr_mul(v, sc);
-        if (fz.st == NTT_ST_PLAIN) {
-            data[addr] = v;
-        } else if (fz.st == NTT_ST_MUL) {
-            data[addr] = fr_mul(v, fz.st_aux[addr & fz.aux_mask]);
-        } else if (fz.st == NTT_ST_COMBINE) {
-            const u64 half = 1ull << (fz.logs - 1);
-            fz.st_dst[addr] = (addr & (2 * half - 1)) < half ? fr_norm(fr_add(fz.st_dst[addr], v)) : v;
-        } else if (addr < fz.cnt) {
-            fz.st_dst[fz.st == NTT_ST_TAKE ? addr : fz.top - addr] = v;
-        }
+        ntt_store_fused(data, addr, v, fz);
     }
     PS_NTT_STAMP(3);
+}
+
+// A cyclic convolution with a stored transform is forward transform -> point-wise product -> inverse transform, and the
+// forward's LAST pass and the inverse's FIRST pass both run on the same contiguous tiles (stride 1, the lowest k stages).
+// k_ntt_mid does both on one visit of the tile: load, k forward stages, times aux, k inverse stages, store -- one HBM round
+// trip and one load / store phase instead of two (a pass costs ~12 us + ~18 us of memory phase whatever it computes:
+// DESIGN.md section 6; the quotient of the reference's key form is ~150 such passes at 2^20).  first / last: the load
+// fusion of the forward's first pass and the store fusion (and scaling) of the inverse's last pass apply here too when the
+// transform fits one tile.
+__global__ void __launch_bounds__(512, 4) k_ntt_mid(Fr* __restrict__ data, int p, int k, int logCols, const Fr* __restrict__ tw_fwd,
+                                                 const Fr* __restrict__ tw_inv, int log_tab, NttFuse fl, NttFuse fs, const Fr* __restrict__ aux,
+                                                 u64 aux_mask, int scale_log) {
+    extern __shared__ __align__(16) unsigned char ntt_smem[];
+    Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
+    const NttTile g{p, 0, k, logCols, (u64)blockIdx.x << logCols};
+    const u32 tile_elems = 1u << (k + logCols);
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u64 addr;
+        u32 slot;
+        ntt_tile_map(g, e, addr, slot);
+        tile[slot] = ntt_load_fused(data, addr, fl);
+    }
+    __syncthreads();
+    ntt_tile_stages<false>(tile, g, tw_fwd, log_tab);
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u64 addr;
+        u32 slot;
+        ntt_tile_map(g, e, addr, slot);
+        tile[slot] = fr_mul(tile[slot], aux[addr & aux_mask]);
+    }
+    __syncthreads();
+    ntt_tile_stages<true>(tile, g, tw_inv, log_tab);
+    Fr sc;
+    if (scale_log) {
+#pragma unroll
+        for (int j = 0; j < FR_L; j++) sc.l[j] = c_fr_inv2pow[scale_log][j];
+    }
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u64 addr;
+        u32 slot;
+        ntt_tile_map(g, e, addr, slot);
+        Fr v = tile[slot];
+        if (scale_log) v = fr_mul(v, sc);
+        ntt_store_fused(data, addr, v, fs);
+    }
 }
 
 #if defined(PS_NTT_PASS8)
@@ -551,6 +631,67 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
             (void)hipMemcpyToSymbol(HIP_SYMBOL(ntt_trace), &none, sizeof(void*));
         }
 #endif
+        done += k;
+    }
+    return hipGetLastError();
+}
+
+// Cyclic convolution of every 2^p-block of `data` with the stored transform `aux` (bit-reversed order, as ntt_run<false>
+// leaves it; index = element index & aux_mask):  data <- INTT(NTT(load(data)) * aux), with the load fusion of `ld_fuse` on the
+// way in and the store fusion of `st_fuse` on the way out.  Same arithmetic, butterfly for butterfly, as
+//     ntt_run<false>(.., {fuse.ld.., st = NTT_ST_MUL, st_aux = aux});  ntt_run<true>(.., {fuse.st..});
+// but the forward's last pass and the inverse's first pass are ONE kernel (k_ntt_mid): 2 npass - 1 passes instead of 2 npass.
+static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p, const NttFuse& ld_fuse, const NttFuse& st_fuse,
+                                  const Fr* aux, u64 aux_mask = ~0ull) {
+    if (p == 0 || p > tb.log_tab || st_fuse.st == NTT_ST_MUL || ld_fuse.st != NTT_ST_PLAIN || st_fuse.ld != NTT_LD_PLAIN) return hipErrorInvalidValue;
+    const int log_total = ilog2_ceil(total);
+    const int max_k = NTT_MAX_K, tile_log = NTT_TILE_LOG;
+    const int npass = p <= tile_log ? 1 : (p + max_k - 1) / max_k;
+    int ks[8];  // forward order (from the top); the inverse walks the same groups back
+    {
+        int left = p;
+        for (int i = 0; i < npass; i++) { ks[i] = (left + (npass - i) - 1) / (npass - i); left -= ks[i]; }
+    }
+    auto shape = [&](int k, int& logCols, unsigned& grid, size_t& smem, unsigned& threads) {
+        logCols = tile_log - k;
+        if (logCols > log_total - k) logCols = log_total - k;
+        if (logCols < 0) logCols = 0;
+        grid = (unsigned)((total >> k) >> logCols);
+        smem = ((size_t)sizeof(Fr) << k) << logCols;
+        threads = (unsigned)std::min<u64>(512, std::max<u64>(64, ((u64)1 << (k + logCols)) >> 2));
+    };
+    int done = 0;
+    for (int i = 0; i + 1 < npass; i++) {  // forward passes above the tile-resident stages
+        const int k = ks[i], logD = p - done - k;
+        int logCols; unsigned grid, threads; size_t smem;
+        shape(k, logCols, grid, smem, threads);
+        const NttFuse fz = i == 0 ? ld_fuse : NttFuse();
+        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.fwd, tb.log_tab, fz, 0);
+        done += k;
+    }
+    const int km = ks[npass - 1];
+    int unscaled = km;
+    {
+        int logCols; unsigned grid, threads; size_t smem;
+        shape(km, logCols, grid, smem, threads);
+        const NttFuse fl = npass == 1 ? ld_fuse : NttFuse(), fs = npass == 1 ? st_fuse : NttFuse();
+        int scale_log = 0;
+        const int next_k = npass > 1 ? ks[npass - 2] : 0;
+        if (npass == 1 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
+        hipLaunchKernelGGL(k_ntt_mid, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.fwd, (const Fr*)tb.inv, tb.log_tab, fl, fs,
+                           aux, aux_mask, scale_log);
+    }
+    done = km;
+    for (int i = npass - 2; i >= 0; i--) {  // inverse passes, upwards
+        const int k = ks[i], logD = done;
+        int logCols; unsigned grid, threads; size_t smem;
+        shape(k, logCols, grid, smem, threads);
+        const NttFuse fz = i == 0 ? st_fuse : NttFuse();
+        unscaled += k;
+        int scale_log = 0;
+        const int next_k = i > 0 ? ks[i - 1] : 0;
+        if (i == 0 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
+        hipLaunchKernelGGL(k_ntt_pass<true>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.inv, tb.log_tab, fz, scale_log);
         done += k;
     }
     return hipGetLastError();

@@ -346,7 +346,8 @@ struct QapTables {
     std::vector<Fr*> zhat_h;     // subproduct tree over the nodes n+1 .. n+np_h
     // work buffers
     Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
-    Fr* s4 = nullptr;            // 8np, short transforms only: the three convolutions of the h-values path as ONE batch
+    Fr* s4 = nullptr;            // 8np: the two interpolations of Groth16's route as ONE batch of transforms (any n, round 4) ...
+    bool batch_h = false;        // ... and, for short transforms only, the three convolutions of the h-values path as a batch of four
     std::vector<void*> owned;
     void free_all() {
         for (void* p : owned) (void)hipFree(p);
@@ -356,7 +357,7 @@ struct QapTables {
 };
 
 #ifndef QT_BATCH_MAX_L
-#define QT_BATCH_MAX_L (1ull << 16)  // transforms up to this length leave most of the chip idle: the h-values path batches its three
+#define QT_BATCH_MAX_L (1ull << 16)  // transforms up to this length leave most of the chip idle: the h-values path batches its three convolutions
 #endif
 #define QT_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
@@ -382,11 +383,9 @@ static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t s
         // prepare, multiply and combine ride on the first load / last store of the two transforms
         NttFuse f;
         f.ld = NTT_LD_UPPER_HALF; f.ld_src = data; f.logs = logs;
-        f.st = NTT_ST_MUL; f.st_aux = zhat[logs]; f.aux_mask = np - 1;
-        QT_TRY(ntt_run<false>(tabs, st, scratch, np * members, logs, f));
         NttFuse g;
         g.st = NTT_ST_COMBINE; g.st_dst = data; g.logs = logs;
-        QT_TRY(ntt_run<true>(tabs, st, scratch, np * members, logs, g));
+        QT_TRY(ntt_conv(tabs, st, scratch, np * members, logs, f, g, zhat[logs], np - 1));
     }
     return hipGetLastError();
 }
@@ -398,12 +397,10 @@ static inline hipError_t interpolate_on_nodes(const NttTables& tabs, hipStream_t
     // t1 = INTT(NTT(y_j / j!, zero-padded) * vhat); data = its first cnt entries, zero up to np
     NttFuse f;
     f.ld = NTT_LD_SCALE_PAD; f.ld_src = y; f.ld_aux = qt.invfact; f.cnt = cnt;
-    f.st = NTT_ST_MUL; f.st_aux = vhat;
-    QT_TRY(ntt_run<false>(tabs, st, qt.t1, 2 * np, lognp + 1, f));
     QT_TRY(hipMemsetAsync(qt.data, 0, sizeof(Fr) * np, st));
     NttFuse g;
     g.st = NTT_ST_TAKE; g.st_dst = qt.data; g.cnt = cnt;
-    QT_TRY(ntt_run<true>(tabs, st, qt.t1, 2 * np, lognp + 1, g));
+    QT_TRY(ntt_conv(tabs, st, qt.t1, 2 * np, lognp + 1, f, g, vhat));
     return newton_to_monomial(tabs, st, np, lognp, zhat, off, qt.data, qt.scratch);
 }
 // values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
@@ -413,29 +410,17 @@ static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_
 
 // Two interpolations on {1..n} as ONE batch (small circuits, where a transform is a handful of workgroups and every launch is
 // latency; qt.s4 = [t1: 2 x 2np | data: 2 x np | scratch: 2 x np]): the coefficients of member b end up in data[b * np ..].
-__global__ void __launch_bounds__(256) k_interp_prep2(Fr* __restrict__ out, const Fr* __restrict__ y0, const Fr* __restrict__ y1,
-                                                      const Fr* __restrict__ invfact, u64 cnt, int logL) {
-    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (2ull << logL)) return;
-    const u64 i = idx & ((1ull << logL) - 1);
-    out[idx] = i < cnt ? fr_mul((idx >> logL) ? y1[i] : y0[i], invfact[i]) : fr_zero();
-}
-__global__ void __launch_bounds__(256) k_interp_take2(Fr* __restrict__ data, const Fr* __restrict__ t1, u64 cnt, int lognp) {
-    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (2ull << lognp)) return;
-    const u64 i = idx & ((1ull << lognp) - 1), b = idx >> lognp;
-    data[idx] = i < cnt ? t1[(b << (lognp + 1)) + i] : fr_zero();
-}
 static inline hipError_t interpolate2_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y0, const Fr* y1,
                                                 Fr* out0, Fr* out1) {
     const u64 np = qt.np, L = 2 * np;
     Fr *t1 = qt.s4, *data = qt.s4 + 2 * L, *scratch = data + 2 * np;
-    hipLaunchKernelGGL(k_interp_prep2, dim3(nblk(2 * L)), dim3(256), 0, st, t1, y0, y1, (const Fr*)qt.invfact, qt.n, qt.lognp + 1);
+    // y_j / j! of both members on the way in, the first n entries of both convolutions on the way out (zero up to np)
     NttFuse f;
-    f.st = NTT_ST_MUL; f.st_aux = qt.vhat; f.aux_mask = L - 1;
-    QT_TRY(ntt_run<false>(tabs, st, t1, 2 * L, qt.lognp + 1, f));
-    QT_TRY(ntt_run<true>(tabs, st, t1, 2 * L, qt.lognp + 1));
-    hipLaunchKernelGGL(k_interp_take2, dim3(nblk(2 * np)), dim3(256), 0, st, data, (const Fr*)t1, qt.n, qt.lognp);
+    f.ld = NTT_LD_SCALE_PAD; f.ld_src = y0; f.ld_src2 = y1; f.ld_aux = qt.invfact; f.cnt = qt.n; f.batch_log = qt.lognp + 1;
+    NttFuse g;
+    g.st = NTT_ST_TAKE; g.st_dst = data; g.cnt = qt.n; g.batch_log = qt.lognp + 1; g.st_member_log = qt.lognp;
+    if (qt.n < np) QT_TRY(hipMemsetAsync(data, 0, sizeof(Fr) * 2 * np, st));
+    QT_TRY(ntt_conv(tabs, st, t1, 2 * L, qt.lognp + 1, f, g, qt.vhat, L - 1));
     QT_TRY(newton_to_monomial(tabs, st, np, qt.lognp, qt.zhat, 0, data, scratch, 2));
     QT_TRY(hipMemcpyAsync(out0, data, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
     QT_TRY(hipMemcpyAsync(out1, data + np, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
@@ -456,25 +441,19 @@ static inline hipError_t quotient_h_values(const NttTables& tabs, hipStream_t st
     if (n < 2) return hipSuccess;
     const Fr* ys[3] = {yA, yB, yC};
     Fr* S[3] = {qt.t1, qt.pa, qt.pb};
-    if (qt.s4) {
+    if (qt.s4 && qt.batch_h) {
         // Short transforms are latency: a 2^11-point transform is two workgroups walking eleven butterfly stages, ~40 us for
         // the forward and inverse pair whatever the chip could do beside it (kernel trace of Groth16Prove on 2^10 constraints:
         // 0.23 of the quotient's 0.37 ms).  The three convolutions share the kernel 1/d, so they run as one batch of four
         // transforms (the fourth is zeros: batches are powers of two) -- one pair of launches instead of three.
         const int logL = qt.lognp + 1;
         hipLaunchKernelGGL(k_lagrange_weights3, dim3(nblk(4 * L)), dim3(256), 0, st, qt.s4, FrPtr3{{yA, yB, yC}}, qt.invfact, n, logL);
-        NttFuse f;
-        f.st = NTT_ST_MUL; f.st_aux = qt.rhat; f.aux_mask = L - 1;
-        QT_TRY(ntt_run<false>(tabs, st, qt.s4, 4 * L, logL, f));
-        QT_TRY(ntt_run<true>(tabs, st, qt.s4, 4 * L, logL));
+        QT_TRY(ntt_conv(tabs, st, qt.s4, 4 * L, logL, NttFuse(), NttFuse(), qt.rhat, L - 1));
         for (int k = 0; k < 3; k++) S[k] = qt.s4 + (u64)k * L;
     } else
     for (int k = 0; k < 3; k++) {
         hipLaunchKernelGGL(k_lagrange_weights, dim3(nblk(L)), dim3(256), 0, st, S[k], ys[k], qt.invfact, n, L);
-        NttFuse f;
-        f.st = NTT_ST_MUL; f.st_aux = qt.rhat;
-        QT_TRY(ntt_run<false>(tabs, st, S[k], L, qt.lognp + 1, f));
-        QT_TRY(ntt_run<true>(tabs, st, S[k], L, qt.lognp + 1));
+        QT_TRY(ntt_conv(tabs, st, S[k], L, qt.lognp + 1, NttFuse(), NttFuse(), qt.rhat));
     }
     hipLaunchKernelGGL(k_h_values, dim3(nblk(n - 1)), dim3(256), 0, st, qt.scratch, (const Fr*)S[0], (const Fr*)S[1], (const Fr*)S[2],
                        (const Fr*)qt.fact2, (const Fr*)qt.invfact, n);
@@ -501,9 +480,7 @@ static inline hipError_t quotient_from_AB(const NttTables& tabs, hipStream_t st,
     QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sp, qt.pp, fa));
     NttFuse fb;
     fb.ld = NTT_LD_PAD; fb.ld_src = B; fb.cnt = n;
-    fb.st = NTT_ST_MUL; fb.st_aux = qt.pa;
-    QT_TRY(ntt_run<false>(tabs, st, qt.pb, Sp, qt.pp, fb));
-    QT_TRY(ntt_run<true>(tabs, st, qt.pb, Sp, qt.pp));
+    QT_TRY(ntt_conv(tabs, st, qt.pb, Sp, qt.pp, fb, NttFuse(), qt.pa));
     // q_i = P_{2n-2-i}, i < n-1, times the inverse series; h_{n-2-i} = (q*g)_i
     if (qt.ph == 0) {  // n = 2: one coefficient, transforms of size 1
         hipLaunchKernelGGL(k_rev_take, dim3(1), dim3(256), 0, st, qt.pa, (const Fr*)qt.pb, 2 * n - 2, n - 1, Sh);
@@ -513,11 +490,9 @@ static inline hipError_t quotient_from_AB(const NttTables& tabs, hipStream_t st,
     }
     NttFuse fq;
     fq.ld = NTT_LD_REV_PAD; fq.ld_src = qt.pb; fq.top = 2 * n - 2; fq.cnt = n - 1;
-    fq.st = NTT_ST_MUL; fq.st_aux = qt.ghat;
-    QT_TRY(ntt_run<false>(tabs, st, qt.pa, Sh, qt.ph, fq));
     NttFuse fh;
     fh.st = NTT_ST_REV_TAKE; fh.st_dst = h_out; fh.top = n - 2; fh.cnt = n - 1;
-    QT_TRY(ntt_run<true>(tabs, st, qt.pa, Sh, qt.ph, fh));
+    QT_TRY(ntt_conv(tabs, st, qt.pa, Sh, qt.ph, fq, fh, qt.ghat));
     return hipGetLastError();
 }
 
@@ -566,7 +541,12 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.scratch, big));
     QT_TRY(qt_alloc(qt, &qt.pa, big));
     QT_TRY(qt_alloc(qt, &qt.pb, big));
-    if (2 * np <= QT_BATCH_MAX_L) QT_TRY(qt_alloc(qt, &qt.s4, 8 * np));
+    // Both interpolations of Groth16's route run as one batch at every size: with twice the workgroups per pass the loads of
+    // one round hide under the butterflies of the other (A/B on one box at 2^20: quotient 10.6 -> 9.9 ms).  The h-values path
+    // batches its three convolutions as FOUR transforms (batches are powers of two) only while that is latency, not work
+    // (at 2^20 the batch of four costs 3.1 ms against 2.5 for three single transforms).
+    QT_TRY(qt_alloc(qt, &qt.s4, 8 * np));
+    qt.batch_h = 2 * np <= QT_BATCH_MAX_L;
     QT_TRY(qt_alloc(qt, &qt.z, n + 1));
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
     // ---- factorials up to 2np - 1 (host; ps_qap_create computes them on a thread of its own) ----

@@ -575,6 +575,13 @@ func NewHipGroth16Multi(hd *HipDevices, tr Groth16Setup, circuit R1CS) *HipGroth
 	defer l.free()
 	defer r.free()
 	defer o.free()
+	// check() panics on a library error: a device that fails after others succeeded must not leak their QAPs and shards
+	done := false
+	defer func() {
+		if !done {
+			hm.Free()
+		}
+	}()
 	for d, c := range hd.ctxs {
 		var q *C.ps_qap
 		cc := c
@@ -593,6 +600,7 @@ func NewHipGroth16Multi(hd *HipDevices, tr Groth16Setup, circuit R1CS) *HipGroth
 			copyTo(unsafe.Pointer(&pk.delta2[0]), affineOf(C.PS_G2, tr.Delta2))
 		}
 	}
+	done = true
 	return hm
 }
 
@@ -622,10 +630,14 @@ func Groth16ProveHIPMulti(hm *HipGroth16Multi, sol Vector) Groth16Proof {
 	cdev := (*C.ps_groth16_device)(C.malloc(C.size_t(len(hm.dev)) * C.size_t(unsafe.Sizeof(hm.dev[0]))))
 	defer C.free(unsafe.Pointer(cdev))
 	devs := (*[1 << 16]C.ps_groth16_device)(unsafe.Pointer(cdev))[:len(hm.dev):len(hm.dev)]
+	var vp *C.int64_t // an empty solution has no first element to point at (the library refuses it by length, not by a Go panic here)
+	if len(vals) > 0 {
+		vp = &vals[0]
+	}
 	for d := range hm.dev {
 		var h *C.ps_scalars
 		cc := hm.dev[d].ctx
-		check(func() C.int { return C.ps_scalars_upload_i64(cc, &vals[0], C.size_t(len(vals)), &h) })
+		check(func() C.int { return C.ps_scalars_upload_i64(cc, vp, C.size_t(len(vals)), &h) })
 		defer C.ps_scalars_free(h)
 		devs[d] = hm.dev[d]
 		devs[d].sol = h

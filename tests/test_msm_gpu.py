@@ -601,12 +601,68 @@ def test_window_table_sums_equal_the_plain_sums(ps_api, ctx, co, pr, name, n, wb
         assert got == want and poly.BlindEval(plain) == want
     vals = [0, 1, -1, 35, -(1 << 62), (1 << 63) - 1, -(1 << 63)][:n] + [int(rng.next() % 2000) - 1000 for _ in range(max(0, n - 7))]
     assert ps_api.Poly.from_values(ctx, vals).BlindEval(tab) == og.to_b(og.blind_eval_i64(vals, raw))
-    if n >= 333:  # an index-range shard of a precomputed array uses the same table
+    if n >= 333:  # an index-range shard of a precomputed array uses the same table (or, from 1024 points on, one of its own)
         first, cnt = n // 3, n // 2
         sc = vectors[0]
         got = ps_api.Poly.upload(ctx, sc[first:first + cnt]).BlindEval(tab.slice(first, cnt))
-        assert ctx.last_msm_info()["buckets"] == 1 << (tab.table_window - 1)
+        assert ctx.last_msm_info()["window_table"] == 1 and (cnt >= 1024 or ctx.last_msm_info()["buckets"] == 1 << (tab.table_window - 1))
         assert got == og.to_b(og.msm_pippenger(co.pack_fr(sc[first:first + cnt]), raw[first * og.nb:(first + cnt) * og.nb], cnt, 4))
+
+
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_index_range_views_get_a_window_table_of_their_own(ps_api, ctx, co, pr, name):
+    """An index-range shard of a key whose table was built for the WHOLE array (an eighth of a 2^20-point key over
+    its 20-bit table reduced 2^19 buckets for 2^17 points): the first sum over such a view builds a table for the view's own
+    length (smaller windows, a fraction of the buckets), later sums and other contexts find it, multi-sums use it when every
+    array of the call has one, the bytes are the oracle's, and ps_points_precompute(p, -1) releases it with the whole table."""
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 36000)
+    n = 1 << 15 if name == "g1" else 1 << 14
+    a = ps_api.Poly.upload(ctx, [rng.fr() for _ in range(n)])
+    whole = ps_api.Points.from_scalars(ctx, gid, a).precompute(16)
+    raw = whole.download()
+    first, cnt = 4099, 2048
+    view = whole.slice(first, cnt)
+    sc = [rng.fr() for _ in range(cnt)]
+    want = og.to_b(og.msm_pippenger(co.pack_fr(sc), raw[first * og.nb:(first + cnt) * og.nb], cnt, 4))
+    poly = ps_api.Poly.upload(ctx, sc)
+    for _ in range(2):  # built by the first sum, found by the second
+        assert poly.BlindEval(view) == want
+        info = ctx.last_msm_info()
+        assert info["window_table"] == 1 and info["window_bits"] < 16 and info["buckets"] == 1 << (info["window_bits"] - 1)
+    view_bits = info["window_bits"]
+    # another context and a second handle on the same range find the same table
+    cx2 = ps_api.Context(0)
+    assert poly.BlindEval(whole.slice(first, cnt)) == want
+    p2 = ps_api.Poly.upload(cx2, sc)
+    assert p2.BlindEval(view) == want and cx2.last_msm_info()["window_bits"] == view_bits
+    cx2.close()
+    # a multi-sum over two views of the same range of two arrays; then with one array that has no table at all (plain plan)
+    other = ps_api.Points.from_scalars(ctx, gid, ps_api.Poly.upload(ctx, [rng.fr() for _ in range(n)])).precompute(16)
+    oraw = other.download()
+    want_o = og.to_b(og.msm_pippenger(co.pack_fr(sc), oraw[first * og.nb:(first + cnt) * og.nb], cnt, 4))
+    assert ps_api.msm_multi(ctx, [view, other.slice(first, cnt)], poly) == [want, want_o]
+    assert ctx.last_msm_info()["window_bits"] == view_bits and ctx.last_msm_info()["window_table"] == 1
+    bare = ps_api.Points.upload(ctx, gid, oraw)
+    assert ps_api.msm_multi(ctx, [view, bare.slice(first, cnt)], poly) == [want, want_o]
+    assert ctx.last_msm_info()["window_table"] == 0
+    # a view almost as long as the array keeps the array's own table (nothing to gain), int64 witnesses over the view table
+    long_view = whole.slice(1, n - 2)
+    sc_long = [rng.fr() for _ in range(n - 2)]
+    got = ps_api.Poly.upload(ctx, sc_long).BlindEval(long_view)
+    assert ctx.last_msm_info()["window_table"] == 1 and (name == "g2" or ctx.last_msm_info()["window_bits"] == 16)
+    assert got == og.to_b(og.msm_pippenger(co.pack_fr(sc_long), raw[og.nb:(n - 1) * og.nb], n - 2, 4))
+    vals = [int(rng.next() % 2000) - 1000 for _ in range(cnt)]
+    assert ps_api.Poly.from_values(ctx, vals).BlindEval(view) == og.to_b(og.blind_eval_i64(vals, raw[first * og.nb:(first + cnt) * og.nb]))
+    # tables off for the context: no table of any kind is read; release: the whole array's plain plan
+    ctx.set_tables(False)
+    try:
+        assert poly.BlindEval(view) == want and ctx.last_msm_info()["window_table"] == 0
+    finally:
+        ctx.set_tables(True)
+    assert poly.BlindEval(view) == want and ctx.last_msm_info()["window_bits"] == view_bits
+    whole.precompute(-1)
+    assert poly.BlindEval(view) == want and ctx.last_msm_info()["window_table"] == 0
 
 
 def test_window_table_in_the_queue_in_multi_sums_and_rebuilt(ps_api, ctx, co, pr):
