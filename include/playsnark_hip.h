@@ -47,8 +47,9 @@ typedef struct ps_qap ps_qap;         /* device-resident sparse QAP + per-n tabl
  * ps_groth16_device, ..) MUST be zero-initialised by the caller (memset or `= {0}`): an optional array that is NULL is
  * "not present", and garbage in a member added by a later revision would be dereferenced.
  *   1  round 1;  2  Lagrange-form key arrays (lxi / lxi2 / lxi_t / lgsi), multi-device entries;
- *   3  ps_msm_info.window_table, ps_msm_set_tail, ps_ctx_set_table_budget, ps_qap_is_valid, ps_microbench_mad */
-#define PS_ABI_VERSION 3
+ *   3  ps_msm_info.window_table, ps_msm_set_tail, ps_ctx_set_table_budget, ps_qap_is_valid, ps_microbench_mad;
+ *   4  ps_points_monomial_to_lagrange; index-range views build window tables of their own (no struct changed) */
+#define PS_ABI_VERSION 4
 int ps_abi_version(void);
 const char* ps_last_error(void);
 const char* ps_version(void);
@@ -317,6 +318,18 @@ typedef struct { /* PHGR13Setup (pinochio.go:28-35) without the toxic waste */
 /* NewPHGR13TrustedSetup (pinochio.go:93-176) with the toxic waste supplied by the caller. */
 int ps_phgr13_setup(ps_ctx* ctx, const ps_qap* q, const ps_phgr13_toxic* tw, ps_phgr13_crs* out);
 void ps_phgr13_crs_free(ps_phgr13_crs* crs); /* frees the 14 arrays */
+
+/* ---- a reference-made key onto the fast route, without the toxic waste ----
+ * The reference's setups emit the monomial arrays only -- Xi, Xi2, XiT (groth16.go:79-97), gsi (pinochio.go:101) -- and a prover
+ * given those interpolates and divides (28 ms per Groth16 proof at 2^20 constraints where the Lagrange form of the same key
+ * takes 18).  ps_groth16_setup emits both forms but needs the toxic waste, which "must be delete[d] after a trusted setup"
+ * (groth16.go:13-14).  This is the one-time conversion of an array {x^i P}, i < cnt, into {l_j(x) P}, j < cnt, over the
+ * group elements alone (the transposed interpolation of csrc/lagrange.cuh: ~230 cnt scalar multiplications of points; seconds
+ * at 2^16 gates, minutes at 2^20).  nodes = 0: the QAP domain 1..n, cnt = n (Xi -> lxi, Xi2 -> lxi2);
+ * nodes = 1: the nodes n+1..2n-1, cnt = n-1 (XiT -> lxi_t, gsi -> lgsi).  Either group.  The result is byte-identical to the
+ * array ps_groth16_setup / ps_phgr13_setup emit from the toxic waste; the caller frees it.  PS_ERR_LENGTH when the array is
+ * not exactly cnt points long. */
+int ps_points_monomial_to_lagrange(ps_ctx* ctx, const ps_qap* q, const ps_points* mono, int nodes, ps_points** out);
 
 /* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */
 typedef struct { /* the verifier's part of Groth16Setup (groth16.go:30-61) */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "ps_msm", "ps_msm_be32", "ps_msm_i64", "ps_msm_launch", "ps_msm_finish", "ps_msm_multi", "ps_points_sum", "ps_point_convert",
     "ps_msm_last_info", "ps_msm_set_window", "ps_msm_set_slice", "ps_msm_set_tail", "ps_microbench_mad", "ps_ctx_set_timing", "ps_msm_last_stage_ms",
     "ps_qap_create", "ps_qap_free", "ps_qap_quotient", "ps_qap_is_valid", "ps_qap_interpolate", "ps_poly_mul",
-    "ps_points_lincomb", "ps_msm_multi_device", "ps_groth16_prove_multi",
+    "ps_points_lincomb", "ps_msm_multi_device", "ps_groth16_prove_multi", "ps_points_monomial_to_lagrange",
     "ps_groth16_setup", "ps_phgr13_setup", "ps_phgr13_crs_free", "ps_groth16_prove", "ps_groth16_prove_shard", "ps_phgr13_prove", "ps_groth16_verify", "ps_phgr13_verify", "ps_pairing_equal", "ps_prove_last_phase_ms",
 ]
 
@@ -164,6 +164,7 @@ def _load():
     lib.ps_poly_mul.argtypes = [vp, vp, vp, pp]
     lib.ps_qap_interpolate.argtypes = [vp, vp, vp, i, pp]
     lib.ps_points_lincomb.argtypes = [i, C.c_char_p, C.c_char_p, sz, C.c_char_p]
+    lib.ps_points_monomial_to_lagrange.argtypes = [vp, vp, vp, i, C.POINTER(vp)]
     lib.ps_msm_multi_device.argtypes = [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, C.c_char_p]
     lib.ps_groth16_prove_multi.argtypes = [C.POINTER(Groth16Device), sz, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.ps_groth16_prove.argtypes = [vp, C.POINTER(Groth16Pk), vp, vp, C.c_char_p, C.c_char_p, C.c_char_p,
@@ -183,5 +184,5 @@ def _load():
 
 
 lib = _load()
-if lib.ps_abi_version() != 3:  # include/playsnark_hip.h PS_ABI_VERSION: the structs above mirror that revision
+if lib.ps_abi_version() != 4:  # include/playsnark_hip.h PS_ABI_VERSION: the structs above mirror that revision
     raise ImportError("libplaysnark_hip.so has ABI %d, this binding is written for 3" % lib.ps_abi_version())

@@ -202,6 +202,14 @@ class Points:
         _check(lib.ps_points_slice(self._h, first, n, C.byref(h)))
         return Points(self.ctx, h, owner=self)
 
+    def to_lagrange(self, qap: "QAP", nodes: int = 0) -> "Points":
+        """This array read as {x^i P} (a monomial-form CRS array of the reference's setups: Xi, Xi2 with nodes = 0; XiT, gsi
+        with nodes = 1) -> {l_j(x) P} on the QAP's interpolation nodes (1..n, or n+1..2n-1), without the secret point
+        (ps_points_monomial_to_lagrange): the one-time conversion that puts a reference-made key on the prover's fast route."""
+        h = C.c_void_p()
+        _check(lib.ps_points_monomial_to_lagrange(qap.ctx._h, qap._h, self._h, nodes, C.byref(h)))
+        return Points(qap.ctx, h)
+
     def precompute(self, window_bits: int = 0) -> "Points":
         """Build the window table 2^(c w) P of this resident array once (ps_points_precompute): later sums over it,
         or over slices of it, share one bucket set.  Returns self."""
@@ -318,6 +326,21 @@ def msm_launch(ctx: Context, points: Points, scalars: Poly):
 def msm_finish(ctx: Context, group: int) -> bytes:
     out = C.create_string_buffer(_WIRE[group])
     _check(lib.ps_msm_finish(ctx._h, out))
+    return out.raw
+
+
+def blind_eval_host(ctx: Context, points: Points, scalars) -> bytes:
+    """Seam S1 as the cgo shim calls it (BlindEvalHIP -> ps_msm_be32 / ps_msm_i64): Poly.BlindEval (algebra.go:348-359) with
+    the scalars still in HOST memory -- 32-byte big-endian rows as `bytes`, or a numpy int64 array of witness values
+    (Value.ToFieldElement, curve.go:17-19).  The upload over PCIe is inside the call; nothing of the caller's is kept."""
+    out = C.create_string_buffer(_WIRE[points.group])
+    if isinstance(scalars, (bytes, bytearray)):
+        _check(lib.ps_msm_be32(ctx._h, points._h, bytes(scalars), len(scalars) // 32, out))
+    else:
+        import numpy as np
+
+        arr = np.ascontiguousarray(scalars, dtype=np.int64)
+        _check(lib.ps_msm_i64(ctx._h, points._h, arr.ctypes.data_as(C.c_void_p), arr.size, out))
     return out.raw
 
 
@@ -499,6 +522,12 @@ class Groth16Setup:
         """The key as the reference's NewGroth16TrustedSetup makes it: the monomial arrays alone."""
         return Groth16Setup(self.Alpha, self.Beta, self.Delta, self.Beta2, self.Delta2, self.Xi, self.Xi2, self.NioLP, self.XiT)
 
+    def with_lagrange(self, qap: "QAP") -> "Groth16Setup":
+        """The same key with its Lagrange-form arrays computed from the monomial ones ALONE (no toxic waste, groth16.go:13-14):
+        what a key made by the reference's NewGroth16TrustedSetup needs once to prove on the fast route."""
+        return Groth16Setup(self.Alpha, self.Beta, self.Delta, self.Beta2, self.Delta2, self.Xi, self.Xi2, self.NioLP, self.XiT,
+                            self.Xi.to_lagrange(qap, 0), self.Xi2.to_lagrange(qap, 0), self.XiT.to_lagrange(qap, 1))
+
     def _struct(self):
         pk = _lib.Groth16Pk()
         for name, src in (("alpha", self.Alpha), ("beta", self.Beta), ("delta", self.Delta),
@@ -569,6 +598,10 @@ class PHGR13EvalKey:
 
     def monomial_only(self) -> "PHGR13EvalKey":
         return PHGR13EvalKey(**{f: getattr(self, f) for f in self.FIELDS})
+
+    def with_lagrange(self, qap: "QAP") -> "PHGR13EvalKey":
+        """The same key with gsi's Lagrange form on the nodes n+1..2n-1 computed from gsi alone (no toxic waste)."""
+        return PHGR13EvalKey(lgsi=self.gsi.to_lagrange(qap, 1), **{f: getattr(self, f) for f in self.FIELDS})
 
     def _struct(self):
         ek = _lib.Phgr13Ek()

@@ -16,6 +16,7 @@
 
 #include "msm.cuh"
 #include "quotient.cuh"
+#include "lagrange.cuh"
 
 namespace ps {
 #include "hostfield.inc"
@@ -38,7 +39,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* ps_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* ps_version(void) { return "playsnark_hip 0.3 (gfx950), ABI 3"; }
+extern "C" const char* ps_version(void) { return "playsnark_hip 0.4 (gfx950), ABI 4"; }
 extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 extern "C" int ps_device_count(void) {
     int n = 0;
@@ -85,6 +86,11 @@ struct ps_ctx {
     DevBuf counts, offs, bsum, keys, ranks, vals, sorted, buckets, parts, segs, wins, heavy, hparts, coarse;
     DevBuf affine_tmp;  // XYZZ points + chain products of k_batch_to_affine (fixed-base multiplications, window tables)
     DevBuf staging;                  // byte staging for uploads / downloads
+    // ps_msm_be32 / ps_msm_i64 (seam S1: one upload per BlindEval call): the converted scalars of the call live in a vector
+    // the context keeps, so a call does not pay a hipMalloc and a hipFree (which synchronises the device) of 32 bytes per
+    // scalar on top of its copy over PCIe
+    struct ps_scalars* up_scalars = nullptr;
+    size_t up_cap = 0;
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
     u32* d_flag = nullptr;           // small device scratch word (bad-point counter etc.)
@@ -268,6 +274,7 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
                       &c->segs, &c->wins, &c->heavy, &c->hparts, &c->vals, &c->coarse, &c->staging, &c->affine_tmp, &c->fb_table[0], &c->fb_table[1]})
         b->release();
     quotient_cache_free(c->qcache);
+    if (c->up_scalars) ps_scalars_free(c->up_scalars);
     if (c->g16_pa) ps_points_free(c->g16_pa);
     if (c->g16_pb) ps_points_free(c->g16_pb);
     if (c->g16_pc) ps_points_free(c->g16_pc);
@@ -341,6 +348,25 @@ extern "C" int ps_scalars_upload(ps_ctx* c, const uint8_t* be32, size_t n, ps_sc
     rc = ps_scalars_from_device_be32(c, c->staging.p, n, out);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // caller's buffer is not retained past return
+    return PS_OK;
+}
+
+// The context's own vector for the scalars of ONE ps_msm_be32 / ps_msm_i64 call: grown when a call needs more, never shrunk,
+// resized in place (the handle is the context's alone and no sum is pending on it between calls).
+static int upload_vector(ps_ctx* c, size_t n, ps_scalars** out) {
+    if (!c->up_scalars || c->up_cap < n) {
+        if (c->up_scalars) { ps_scalars_free(c->up_scalars); c->up_scalars = nullptr; c->up_cap = 0; }
+        const size_t cap = n + n / 8 + 64;
+        int rc = scalars_alloc(c, cap, &c->up_scalars);
+        if (rc) return rc;
+        c->up_cap = cap;
+    }
+    ps_scalars* s = c->up_scalars;
+    s->n = n;
+    s->first = 0;
+    s->max_bits = 255;
+    s->neg_small = false;
+    *out = s;
     return PS_OK;
 }
 
@@ -1640,20 +1666,51 @@ extern "C" int ps_msm(ps_ctx* c, const ps_points* pts, const ps_scalars* sc, uin
     if (rc) return rc;
     return ps_msm_finish(c, out);
 }
+// Seam S1 (Poly.BlindEval, algebra.go:348-359, as the shim calls it): the scalars cross PCIe inside the call -- 32 bytes each
+// from pageable memory, ~0.6 ms per 2^20 at the link's rate, and nothing of the sum can start before its digits are sorted, so
+// that time does not hide.  What the call does NOT pay any more (round 4): a hipMalloc and a hipFree of the converted vector
+// (the free synchronises the device), and a second synchronisation -- ps_msm's own wait for the result covers the copy.
 extern "C" int ps_msm_be32(ps_ctx* c, const ps_points* pts, const uint8_t* be32, size_t n, uint8_t* out) {
-    ps_scalars* s = nullptr;
-    int rc = ps_scalars_upload(c, be32, n, &s);
+    if (!c || !pts || !out || (n && !be32)) return fail(PS_ERR_ARG, "ps_msm_be32: NULL argument");
+    if (c->q_len) return fail(PS_ERR_ARG, "ps_msm: sums are pending on this context (ps_msm_finish them first)");
+    if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->staging.ensure(32 * n + 32);
     if (rc) return rc;
+    ps_scalars* s = nullptr;
+    if ((rc = upload_vector(c, n, &s))) return rc;
+    // (no sum is pending and every earlier call returned after its result: the staging buffer and the vector are free)
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(c->staging.p, be32, 32 * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scalars_from_be32, dim3(nblocks(n)), dim3(256), 0, c->stream, (const uint8_t*)c->staging.p, (u32)n, (u32*)s->st->p);
+        HIP_TRY(hipGetLastError());
+    }
+    if (storage_mark_ready(s->st, c->stream)) return fail(PS_ERR_HIP, "ps_msm_be32: event record failed");
     rc = ps_msm(c, pts, s, out);
-    ps_scalars_free(s);
+    if (rc) (void)hipStreamSynchronize(c->stream);  // the caller's buffer is not read past return, error or not
     return rc;
 }
 extern "C" int ps_msm_i64(ps_ctx* c, const ps_points* pts, const int64_t* v, size_t n, uint8_t* out) {
-    ps_scalars* s = nullptr;
-    int rc = ps_scalars_upload_i64(c, v, n, &s);
+    if (!c || !pts || !out || (n && !v)) return fail(PS_ERR_ARG, "ps_msm_i64: NULL argument");
+    if (c->q_len) return fail(PS_ERR_ARG, "ps_msm: sums are pending on this context (ps_msm_finish them first)");
+    if (n >= (1ull << 31)) return fail(PS_ERR_ARG, "vector too long");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->staging.ensure(8 * n + 32);
     if (rc) return rc;
+    ps_scalars* s = nullptr;
+    if ((rc = upload_vector(c, n, &s))) return rc;
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(c->staging.p, v, 8 * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_scalars_from_i64, dim3(nblocks(n)), dim3(256), 0, c->stream, (const int64_t*)c->staging.p, (u32)n, (u32*)s->st->p);
+        HIP_TRY(hipGetLastError());
+    }
+    bool any_neg = false;
+    for (size_t i = 0; i < n; i++) any_neg |= v[i] < 0;
+    s->max_bits = 64;
+    s->neg_small = any_neg;
+    if (storage_mark_ready(s->st, c->stream)) return fail(PS_ERR_HIP, "ps_msm_i64: event record failed");
     rc = ps_msm(c, pts, s, out);
-    ps_scalars_free(s);
+    if (rc) (void)hipStreamSynchronize(c->stream);
     return rc;
 }
 extern "C" int ps_msm_last_info(ps_ctx* c, ps_msm_info* out) {
@@ -1762,4 +1819,5 @@ extern "C" int ps_debug_ntt_trace(unsigned long long* out, int* meta) {
 }
 #endif
 #include "prove.inc"
+#include "lagrange.inc"
 #include "pairing.inc"

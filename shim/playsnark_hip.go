@@ -380,6 +380,23 @@ func NewHipGroth16(tr Groth16Setup, q *HipQAP) *HipGroth16 {
 	return hs
 }
 
+// ToLagrange puts a key made by the reference's NewGroth16TrustedSetup (monomial arrays only) onto the prover's fast route
+// WITHOUT the toxic waste, which "must be delete[d] after a trusted setup" (groth16.go:13-14): Xi, Xi2 and XiT are converted
+// on the GPU into l_j(x) G1, l_j(x) G2 and lambda_k(x) t(x)/delta G1 over the group elements alone
+// (ps_points_monomial_to_lagrange: a transposed interpolation, seconds at 2^16 gates, minutes at 2^20 -- once per key).
+// Afterwards Groth16ProveHIP needs no interpolation and no division; the proof bytes do not change.
+func (hs *HipGroth16) ToLagrange() {
+	if hs.pk.lxi != nil {
+		return
+	}
+	var lxi, lxi2, lxit *C.ps_points
+	call(func() C.int { return C.ps_points_monomial_to_lagrange(hipCtx, hs.qap.h, hs.xi, 0, &lxi) })
+	call(func() C.int { return C.ps_points_monomial_to_lagrange(hipCtx, hs.qap.h, hs.xi2, 0, &lxi2) })
+	call(func() C.int { return C.ps_points_monomial_to_lagrange(hipCtx, hs.qap.h, hs.xiT, 1, &lxit) })
+	hs.lagrange = []*C.ps_points{lxi, lxi2, lxit}
+	hs.pk.lxi, hs.pk.lxi2, hs.pk.lxi_t = lxi, lxi2, lxit
+}
+
 // NewHipGroth16FromToxicWaste builds the device-resident key from the five scalars the reference's setup keeps
 // "for testing and learning purpose" (groth16.go:13-27, tr.tw): ps_groth16_setup recomputes every CRS array on the
 // GPU -- the same points, byte for byte, as tr.Xi, tr.Xi2, tr.IoLP, tr.NioLP, tr.XiT -- and emits the SAME CRS in

@@ -665,6 +665,33 @@ def test_index_range_views_get_a_window_table_of_their_own(ps_api, ctx, co, pr, 
     assert poly.BlindEval(view) == want and ctx.last_msm_info()["window_table"] == 0
 
 
+@pytest.mark.parametrize("name", ["g1", "g2"])
+def test_blind_eval_with_host_scalars_is_seam_s1(ps_api, ctx, co, pr, name):
+    """ps_msm_be32 / ps_msm_i64 -- Poly.BlindEval (algebra.go:348-359) as the cgo shim calls it, scalars in host memory: the
+    context keeps ONE upload vector between calls (no allocation per call), so lengths that grow, shrink and repeat, both
+    scalar forms in turn, a table-carrying array, an empty sum and the length-mismatch panic all go through it."""
+    import numpy as np
+
+    gid, og = _grp(ps_api, co, name)
+    rng = _rng(pr, 37000)
+    nmax = 3000
+    raw = og.gen_points(rng.fr(), rng.fr(), nmax)
+    pts = ps_api.Points.upload(ctx, gid, raw).precompute(0)
+    for n in (5, 3000, 64, 1, 2999, 700, 700):
+        sc = [rng.fr() for _ in range(n)]
+        view = pts.slice(0, n)
+        want = og.to_b(og.msm_pippenger(co.pack_fr(sc), raw[:n * og.nb], n, 4))
+        assert ps_api.blind_eval_host(ctx, view, co.pack_fr(sc)) == want
+        vals = [int(rng.next() % 2001) - 1000 for _ in range(n)]
+        vals[0] = -(1 << 63)
+        assert ps_api.blind_eval_host(ctx, view, np.array(vals, dtype=np.int64)) == og.to_b(og.blind_eval_i64(vals, raw[:n * og.nb]))
+        assert ps_api.Poly.upload(ctx, sc).BlindEval(view) == want  # device-resident scalars in between
+    ident = bytes([0x40]) + bytes(og.nb - 1)
+    assert ps_api.blind_eval_host(ctx, pts.slice(0, 0), b"") == ident
+    with pytest.raises(ps_api.LengthMismatch):
+        ps_api.blind_eval_host(ctx, pts, co.pack_fr([1, 2, 3]))
+
+
 def test_window_table_in_the_queue_in_multi_sums_and_rebuilt(ps_api, ctx, co, pr):
     """Tables in ps_msm_launch / ps_msm_finish bursts, in ps_msm_multi (all arrays with tables of one window size: the
     table plan; otherwise the plain plan), with ps_msm_set_window forcing the plain path, and rebuilt for another size."""

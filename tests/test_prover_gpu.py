@@ -189,6 +189,53 @@ def test_phgr13_proof_bit_identical(ps_api, ctx, co, pr, n):
     assert proof.hs == co.G1.to_b(co.G1.mul(pr.poly_eval(want.h, setup.t.s)))
 
 
+@pytest.mark.parametrize("n", [4, 37, 64, 65, 200, 1500])
+def test_monomial_key_to_lagrange_form_without_toxic_waste(ps_api, ctx, co, pr, n):
+    """ps_points_monomial_to_lagrange: the monomial arrays the reference's setups emit -- Xi, Xi2, XiT
+    (groth16.go:79-97), gsi (pinochio.go:101) -- turned into their Lagrange form over the group elements alone (the toxic
+    waste "must be delete[d]", groth16.go:13-14).  Byte-identical to the arrays the device setup computes FROM the toxic
+    waste (themselves checked against the oracle in test_groth16_trusted_setup_on_device), for both node sets and both groups;
+    a key converted this way proves the oracle's proof on the route without interpolation; wrong lengths are BlindEval's panic."""
+    from oracle import restate as rs
+
+    rng = pr.SplitMix64(SEED + 777 + n)
+    if n == 4:
+        c, wit = rs.toy_circuit()
+        sol = [pr.fr(v) for v in wit]
+    else:
+        c, sol = rs.synthetic_circuit(n + (-n % 4))  # 40, 64, 68, 200, 1500 gates: n < np, n = np, a first tree level, several
+    n = len(c.left)
+    tox = [rng.fr() for _ in range(5)]
+    q = _upload_circuit(ps_api, ctx, c)
+    tr, _vk = ps_api.NewGroth16TrustedSetup(q, *tox)
+    conv = tr.monomial_only().with_lagrange(q)
+    assert conv.LXi.download() == tr.LXi.download()
+    assert conv.LXi2.download() == tr.LXi2.download()
+    assert conv.LXiT.download() == tr.LXiT.download()
+    r, s = rng.fr(), rng.fr()
+    dsol = ps_api.Poly.upload(ctx, sol)
+    got = ps_api.Groth16Prove(conv, q, dsol, r, s)
+    assert ctx.last_prove_phase_ms()["quotient"] >= 0
+    if n <= 256:
+        ref = rs.groth16_prove(rs.groth16_setup(c, *tox), c, sol, r, s, fast=n > 16)
+        assert (got.A, got.B, got.C) == (ref.A, ref.B, ref.C)
+    else:
+        mono = ps_api.Groth16Prove(tr.monomial_only(), q, dsol, r, s)
+        assert (got.A, got.B, got.C) == (mono.A, mono.B, mono.C)
+    if n >= 4:
+        tox8 = [rng.fr() for _ in range(8)]
+        ek, _pvk = ps_api.NewPHGR13TrustedSetup(q, *tox8)
+        conv_ek = ek.monomial_only().with_lagrange(q)
+        assert conv_ek.lgsi.download() == ek.lgsi.download()
+        a, b = ps_api.PHGR13Prove(conv_ek, q, dsol), ps_api.PHGR13Prove(ek.monomial_only(), q, dsol)
+        for f in ps_api.PHGR13Proof.FIELDS:
+            assert getattr(a, f) == getattr(b, f), f
+    with pytest.raises(ps_api.LengthMismatch):
+        tr.Xi.to_lagrange(q, 1)  # n points where the nodes n+1..2n-1 take n-1
+    with pytest.raises(ps_api.LengthMismatch):
+        tr.XiT.to_lagrange(q, 0)
+
+
 @pytest.mark.parametrize("n", [4, 37, 200])
 def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     """NewGroth16TrustedSetup (groth16.go:64-101) on the device against the oracle: every CRS array
