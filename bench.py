@@ -794,6 +794,24 @@ def extras(api, ctx, args, mad_peak):
                            "note": "Groth16: mean of 10 proofs after one warm-up; PHGR13: median of 10 after two"}
     del tr, vk, ek, pvk, q, dsol
 
+    # ---- a reference-made key onto the fast route without the toxic waste: the one-time monomial -> Lagrange conversion of
+    # Xi, Xi2, XiT over the group elements (ps_points_monomial_to_lagrange), timed at 2^16 constraints (2^20: ~100 s,
+    # profiles/r04_key_to_lagrange.txt), each array compared with the one the setup computed from the toxic waste ----
+    nk = 1 << 16
+    nvars, L, Rm, O, sol = synthetic_r1cs(nk)
+    q = api.QAP.from_csr(ctx, nvars, nvars - 3, L, Rm, O)
+    tr, vk = api.NewGroth16TrustedSetup(q, fr(), fr(), fr(), fr(), fr())
+    ctx.sync()
+    t0 = time.perf_counter()
+    conv = tr.monomial_only().with_lagrange(q)
+    ctx.sync()
+    conv_s = time.perf_counter() - t0
+    same = (conv.LXi.download() == tr.LXi.download() and conv.LXi2.download() == tr.LXi2.download()
+            and conv.LXiT.download() == tr.LXiT.download())
+    out["groth16_key_to_lagrange_2p16"] = {"seconds": conv_s, "byte_identical_to_setup_arrays": bool(same),
+                                           "note": "Xi (G1), Xi2 (G2), XiT (G1) of a 2^16-constraint key; once per key"}
+    del tr, vk, conv, q
+
     # ---- the regime the reference itself lives in (Vector = []int, algebra.go:13): 2^20 booleanity gates b*b = b, a witness
     # of random bits uploaded as int64 -- short scalars, and wire values that are all 0 or 1 ----
     import numpy as np

@@ -179,3 +179,17 @@ def test_foreign_callers_prove_the_toy_circuit(tmp_path, lang):
     res = subprocess.run([exe, _fixture_file(tmp_path)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ok" in res.stdout
+
+
+def test_shipped_library_does_not_use_the_stream_ordered_allocator():
+    """Round 2 lost a kernel's writes to staging memory from hipMallocAsync (cause never established
+    outside the library: tools/malloc_async_repro.hip does not reproduce it).  The shipped build stages through buffers the
+    context keeps; the stream-ordered variant survives only behind -DPS_AFFINE_TMP_ASYNC for the probe.  This pins it: the
+    shared library imports neither hipMallocAsync nor hipFreeAsync."""
+    import subprocess
+
+    lib = os.path.join(ROOT, "playsnark_amd", "libplaysnark_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "hipMallocAsync" not in syms and "hipFreeAsync" not in syms

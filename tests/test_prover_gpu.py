@@ -236,6 +236,32 @@ def test_monomial_key_to_lagrange_form_without_toxic_waste(ps_api, ctx, co, pr, 
         tr.XiT.to_lagrange(q, 0)
 
 
+def test_monomial_key_to_lagrange_form_at_2pow16(ps_api, ctx, co, pr):
+    """The conversion at 2^16 constraints (VERDICT r3 item 6's spot check, here the whole arrays): Xi, Xi2 and XiT of a
+    device-made key, converted without the toxic waste, are byte for byte the Lagrange-form arrays the setup computed from
+    it; the converted key proves the bytes of the monomial key's proof."""
+    import time
+
+    from oracle import restate as rs
+
+    n = 1 << 16
+    c, sol = rs.synthetic_circuit(n)
+    c.nbIO = c.nbVars - 3
+    rng = pr.SplitMix64(SEED + 7777)
+    q = _upload_circuit(ps_api, ctx, c)
+    tr, _vk = ps_api.NewGroth16TrustedSetup(q, *[rng.fr() for _ in range(5)])
+    t0 = time.time()
+    conv = tr.monomial_only().with_lagrange(q)
+    print("[perf] monomial -> Lagrange form of a 2^16-constraint Groth16 key (Xi, Xi2, XiT): %.1f s" % (time.time() - t0))
+    assert conv.LXi.download() == tr.LXi.download()
+    assert conv.LXi2.download() == tr.LXi2.download()
+    assert conv.LXiT.download() == tr.LXiT.download()
+    r, s = rng.fr(), rng.fr()
+    dsol = ps_api.Poly.upload(ctx, sol)
+    a, b = ps_api.Groth16Prove(conv, q, dsol, r, s), ps_api.Groth16Prove(tr.monomial_only(), q, dsol, r, s)
+    assert (a.A, a.B, a.C) == (b.A, b.B, b.C)
+
+
 @pytest.mark.parametrize("n", [4, 37, 200])
 def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     """NewGroth16TrustedSetup (groth16.go:64-101) on the device against the oracle: every CRS array
@@ -721,6 +747,18 @@ def test_tables_that_do_not_fit_fall_back_to_the_plain_plan(ps_api, co, pr):
                 assert getattr(gp, f) == getattr(want_p, f), f
             assert cx.last_msm_info()["window_table"] == expect_table
         assert (ek.vs.table_window > 0) == bool(expect_table)
+        if not expect_table:
+            # The mark a context with a small budget leaves on a SHARED array is not for ever: it records what that
+            # context had to offer, and a context with more -- here the automatic budget -- asks again and gets its tables.
+            cx2 = ps_api.Context(0)
+            q2 = _upload_circuit(ps_api, cx2, c)
+            gp2 = ps_api.PHGR13Prove(ek, q2, ps_api.Poly.upload(cx2, sol))
+            for f in ps_api.PHGR13Proof.FIELDS:
+                assert getattr(gp2, f) == getattr(want_p, f), f
+            assert cx2.last_msm_info()["window_table"] == 1 and ek.vs.table_window > 0
+            cx2.close()
+            for arr in (ek.vs, ek.ws, ek.ys, ek.vas, ek.was, ek.yas, ek.gsi, ek.vbs):
+                arr.drop_table()
         # an explicit request is still honoured (and still an error when it cannot be)
         if not expect_table:
             ek.vs.precompute(-1)   # clears the "declined" mark
