@@ -41,9 +41,10 @@ MADS_PER_MIXED_ADD = {"g1": 3542, "g2": 2 * 5292}  # 8M+2S: 6*392 + 588 + 2*301;
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8 TB/s spec
 BYTES_PER_SCALAR_MUL = {"g1": 96 + 32, "g2": 192 + 32}  # one affine point + one scalar
 ACC_KERNEL = {"g1": "k_accumulate<Fp>", "g2": "k_accumulate<Fp2s>"}
-PMC_FILE = {"g1": "pmc_accumulate.json"}  # rocprofv3 --pmc passes of the G1 accumulation; none were collected for G2
-FR_MADS_PER_BUTTERFLY = 200                        # one 10-limb Montgomery product (field.cuh fr_mul)
-FR_BYTES = 40                                      # device layout of one Fr element
+PMC_FILE = {"g1": "pmc_accumulate.json", "g2": "pmc_accumulate_g2.json"}  # rocprofv3 --pmc passes of the accumulation kernels (tools/collect_profiles.sh)
+FR_MADS_PER_BUTTERFLY = 200                        # one 10-limb Montgomery product (field.hpp fr_mul)
+FR_BYTES = 40                                      # device layout of one Fr element (10 x 28-bit limbs)
+FR_ALGO_BYTES = 32                                 # algorithmic bytes per element and transform = 2 * K * 32 B
 
 
 def uniform_scalars_be32(n: int, seed: int):
@@ -301,12 +302,13 @@ def reference_algorithm_baseline(points_raw: bytes, scalars_be32: bytes):
 def quotient_work(n: int):
     """Algorithmic traffic and butterflies of the Groth16-route quotient at n gates:
     per interpolation one convolution of 2^(p+1) and levels 7..p of batched transforms over 2^p elements;
-    then five transforms of 2^(p+1) for the product and the division.  One read + one write per transform."""
+    then five transforms of 2^(p+1) for the product and the division.  One read + one write of 32 B per element and
+    transform (SURVEY 8d's figure; the device layout is 40 B)."""
     p = max(6, (n - 1).bit_length())
     np_ = 1 << p
     elems = 2 * (2 * 2 * np_ + sum(2 * np_ for _ in range(7, p + 1))) + 5 * 2 * np_
     bfly = 2 * (2 * np_ * (p + 1) + sum(np_ * logs for logs in range(7, p + 1))) + 5 * np_ * (p + 1)
-    return elems * 2 * FR_BYTES, bfly
+    return elems * 2 * FR_ALGO_BYTES, bfly
 
 
 def launch_ranks(args) -> int:
@@ -511,7 +513,7 @@ def main():
         bytes_per_mul = BYTES_PER_SCALAR_MUL[g]
         achieved = n * bytes_per_mul / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        pmc_name = PMC_FILE.get(g)  # (no PMC passes were collected for the G2 accumulation: `traffic` stays null there)
+        pmc_name = PMC_FILE.get(g)
         pmc_path = os.path.join(ROOT, "profiles", pmc_name) if pmc_name else ""
         if pmc_name and os.path.exists(pmc_path) and not strong and args.log2n == 20 and args.scalars == "uniform":
             try:
@@ -733,7 +735,9 @@ def extras(api, ctx, args, mad_peak):
             "algorithmic_bytes": qbytes, "achieved_GBps": qbytes / (quot_ms * 1e-3) / 1e9,
             "frac_hbm": qbytes / (quot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "butterflies": bfly, "frac_mad_peak": bfly * FR_MADS_PER_BUTTERFLY / (quot_ms * 1e-3) / mad_peak,
-            "note": "one read + one write of 40 B per element and transform; the passes are instruction-bound (DESIGN.md section 6)",
+            "device_bytes": qbytes * FR_BYTES // FR_ALGO_BYTES,
+            "note": "algorithmic bytes at SURVEY 8d's 32 B per element and transform (one read + one write; the device layout is 40 B: "
+                    "device_bytes); the passes are bound by instruction issue (DESIGN.md section 6)",
         },
     }
     del tr, vk, proof

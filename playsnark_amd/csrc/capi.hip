@@ -14,9 +14,9 @@
 #include <string>
 #include <vector>
 
-#include "msm.cuh"
-#include "quotient.cuh"
-#include "lagrange.cuh"
+#include "msm.hpp"
+#include "quotient.hpp"
+#include "lagrange.hpp"
 
 namespace ps {
 #include "hostfield.inc"
@@ -1025,7 +1025,7 @@ static int msm_sort(ps_ctx* c, const ps_scalars* sc, const MsmPlan& pl, bool tim
     }
     const dim3 dgrid((unsigned)((n + DIGITS_CHUNK - 1) / DIGITS_CHUNK), (unsigned)pl.W);
     const int fold_neg = sc->neg_small ? 1 : 0, single = pl.sets == 1 ? 1 : 0;
-    if (G <= SORT_MAX_BUCKETS) {  // two-level counting sort, no per-entry global atomics (msm.cuh 1'-3')
+    if (G <= SORT_MAX_BUCKETS) {  // two-level counting sort, no per-entry global atomics (msm.hpp 1'-3')
         int fb = 5;  // fine bits: as few as keep the coarse bins within SORT_MAX_COARSE
         while (((G + (1ull << fb) - 1) >> fb) > SORT_MAX_COARSE) fb++;
 #if defined(PS_TAIL_TUNE)
@@ -1124,7 +1124,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
     const u64 G = pl.G;
     const u32 nthreads_acc = (u32)((total + pl.M - 1) / pl.M);
     ReducePlan rp = reduce_plan(pl.NB);
-    if (pl.qtail) {  // row sums and column sums in `segs`, c results per set: [S, W_0 .. W_{c-2}] (qtail.cuh)
+    if (pl.qtail) {  // row sums and column sums in `segs`, c results per set: [S, W_0 .. W_{c-2}] (qtail.hpp)
         rp.small = false;
         rp.njobs = (u32)pl.c;
         rp.nblk = 1;
@@ -1187,7 +1187,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         const u32* hlist = hcount + 1;
         u32* job_base = (u32*)wc->heavy.p + 1 + max_heavy;
         hipLaunchKernelGGL(k_heavy_jobs, dim3(1), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc, hcount, hlist, job_base, heavy_npb);
-        // two levels of quad trees for every plan (qtail.cuh): the one-lane kernels of rounds 1-2 (jobs of 1024 slices, strided
+        // two levels of quad trees for every plan (qtail.hpp): the one-lane kernels of rounds 1-2 (jobs of 1024 slices, strided
         // chains, an 8-level LDS tree of 14-36 us additions) took 0.43 ms for the 2^19 ones of a boolean witness at 2^20 points
         hipLaunchKernelGGL(k_qfixup_heavy_part<KF>, dim3(1024), dim3(256), 0, st, (const u32*)c->offs.p, (u32)G, pl.M, nthreads_acc,
                            (const Xyzz<F>*)wc->parts.p,
@@ -1202,7 +1202,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
         Xyzz<F>* lvl = runs + nseg_total;
         Xyzz<F>* pieces = lvl + 5 * (size_t)per_role;
         if (pl.qtail) {
-            // row / column sums, then the bit sums of both (qtail.cuh); small sets: the bit sums straight from the buckets
+            // row / column sums, then the bit sums of both (qtail.hpp); small sets: the bit sums straight from the buckets
             constexpr u32 QGL = QTraits<KF>::GL, QNP = 512 / QGL;
             const int cb = pl.c - 1, s = pl.rc_s;
             const u32 rows = 1u << (cb - s), cols = 1u << s;
@@ -1233,7 +1233,7 @@ static int msm_points_t(ps_ctx* c, ps_ctx* wc, const ps_points* pts, size_t n, c
                                nseg_total, accs, runs);
             if (pl.hybrid && rp.segs >= 64) {
                 // Behind the 8-bucket running sums the parallelism is gone (2^16 segments at 2^20 points) and what is left is
-                // depth: sum = sum_s acc_s + 8 sum_s s run_s, the second sum by rows, columns and bits of s on quads (qtail.cuh)
+                // depth: sum = sum_s acc_s + 8 sum_s s run_s, the second sum by rows, columns and bits of s on quads (qtail.hpp)
                 // -- the same 4 + kb results [A, W_0, W_1, ..] the pyramid leaves ([A, Q0, Q1, Q2, T_0, ..]), 9 + 8 quad additions
                 // deep instead of 7 + 14 + 6 one-lane ones: 0.45 -> 0.13 ms of a lone 2^20-point sum.
                 constexpr u32 QGL = QTraits<KF>::GL, QNP = 256 / QGL;  // 256-thread blocks: one fits where ONE accumulation block retired
@@ -1285,7 +1285,7 @@ static bool table_usable(const ps_ctx* c, const ps_points* pts, size_t n, int ma
     return st->table.load(std::memory_order_acquire) && !c->forced_c && n < (1ull << ENTRY_W_SHIFT) && max_bits / st->table_c + 1 <= st->table_W;
 }
 // Behind the accumulation the chip is mostly idle and a sum's time is the depth of its dependency chain, so the tail runs as
-// trees of lane-cooperative additions (qtail.cuh) wherever that costs little lane-time.  Short sums (fewer than
+// trees of lane-cooperative additions (qtail.hpp) wherever that costs little lane-time.  Short sums (fewer than
 // PS_QTAIL_MAX_ENTRIES digits) also get slices as short as keeps one wave per SIMD busy and a tree fix-up.
 // forced: 0 automatic, 1 the chains of round 2 throughout, 2 the trees wherever they apply.
 #ifndef PS_QTAIL_MAX_ENTRIES
@@ -1419,7 +1419,7 @@ static void msm_fold_host(ps_ctx* c, const MsmPlan& pl, int slot, uint8_t* out) 
     const Xyzz<F>* res = (const Xyzz<F>*)((const char*)c->h_pinned + (size_t)slot * PS_PINNED_SLOT);
     Xyzz<H> acc = xyzz_identity<H>();
     if (pl.sets == 1) {
-        // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.cuh section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
+        // the reduction leaves A, Q0, Q1, Q2, T_0 .. T_{kb-1} (msm.hpp section 6): sum = A + 8 (Q0 + 2 Q1 + 4 Q2 + 8 sum_k 2^k T_k)
         const ReducePlan rp = reduce_plan(pl.NB);
         if (pl.qtail) {  // [S, W_0 .. W_{c-2}] of k_qreduce_bits: sum = S + sum_k 2^k W_k
             for (int j = pl.c - 1; j >= 1; j--) {

@@ -9,12 +9,12 @@
 // Point.Mul/Point.Add loop (algebra.go:355-357) must hold for *all* inputs, including
 // repeated points and adversarial scalars.
 //
-// Lazy-limb discipline (field.cuh): coordinates stored in an accumulator are kept at limb class
+// Lazy-limb discipline (field.hpp): coordinates stored in an accumulator are kept at limb class
 // ~1 by f_norm() on X3 / Y3 (ZZ, ZZZ are multiplication outputs); every product below then sees
 // operand classes whose product is <= 4 and values <= 6p, inside f_mul's contract (<= 8, <= 16p).
 // The rare exceptional branches are out of line so the hot loop stays small.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace ps {
 

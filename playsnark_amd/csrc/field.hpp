@@ -512,7 +512,7 @@ PS_INL Fp f_mul2add2sub(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, 
 
 // sum_k (+/-) a_k b_k under ONE Montgomery reduction -- the same column sums as f_mul / f_mul2sub / f_mul2add /
 // f_mul2add2sub, hence the same limbs bit for bit, but written for a wave that is ALONE on its SIMD (the lane-cooperative
-// additions of the short sums' tail, qtail.cuh): every column keeps its own 64-bit accumulator, so the 196 multiply-adds
+// additions of the short sums' tail, qtail.hpp): every column keeps its own 64-bit accumulator, so the 196 multiply-adds
 // of a product are independent of each other and the only serial chain is the 14 Montgomery digits (about five dependent
 // instructions each).  The product-scanning forms above run all 392 multiply-adds of a product through one accumulator:
 // fine when two waves share a SIMD or a thread has several products in flight, 2 x slower when neither holds (measured:
@@ -1089,7 +1089,7 @@ PS_INL Fp2s f_mul2sub(const Fp2s& a, const Fp2s& b, const Fp2s& c, const Fp2s& d
     const Fp an = f_norm(a.v), bn = f_norm(b.v), cn = f_norm(c.v), dn = f_norm(d.v);
     return Fp2s{f_mul2add2sub(an, pair_bcast0(bn), pair_cross(an), pair_bcast1(bn), cn, pair_bcast0(dn), pair_cross(cn), pair_bcast1(dn))};
 }
-// the same two forms with independent column accumulators (f_mulsum_ilp): the lane-cooperative additions of qtail.cuh
+// the same two forms with independent column accumulators (f_mulsum_ilp): the lane-cooperative additions of qtail.hpp
 PS_INL Fp2s f_mul_ilp(const Fp2s& a, const Fp2s& b) {
     const Fp x[2] = {a.v, pair_cross(a.v)}, y[2] = {pair_bcast0(b.v), pair_bcast1(b.v)};
     const bool neg[2] = {false, false};

@@ -8,7 +8,7 @@
 // reference-made key onto the fast route: a one-time linear map over group elements.
 //
 // How.  For every polynomial a of degree < cnt with values y on the nodes,  sum_i a_i (x^i P) = sum_j y_j (l_j(x) P), and
-// a = M y with M the values -> monomial map of quotient.cuh (interpolate_on_nodes):
+// a = M y with M the values -> monomial map of quotient.hpp (interpolate_on_nodes):
 //     M = T_top ... T_7 . B . [pad] . C . D        D: y_j / j!     C: convolution with (-1)^k / k! (Newton coefficients)
 //                                                  B: Newton -> monomial on blocks of 64      T_s: N = N_left + Z_left N_right
 // so the Lagrange-form points are  L = M^T G = D^T C^T [take] B^T T_7^T ... T_top^T G: the SAME stages transposed (Tellegen),
@@ -23,8 +23,8 @@
 // once per key.  Every point stays in XYZZ form between stages (no inversions); one batch normalisation at the end gives the
 // same canonical affine bytes ps_groth16_setup emits for l_j(x) P (tests/test_prover_gpu.py).
 #pragma once
-#include "msm.cuh"
-#include "quotient.cuh"
+#include "msm.hpp"
+#include "quotient.hpp"
 
 namespace ps {
 
@@ -72,7 +72,7 @@ __device__ inline Xyzz<KF> ec_mul_fr(const Xyzz<KF>& p, const Fr& s_mont) {
 }
 
 // One stage of the NTT over points, in place: `total` points = a batch of transforms of 2^p, half-distance 2^logh.
-// Indexing and twiddles are those of the scalar transform (ntt.cuh, k_ntt_pass): forward = Cooley-Tukey (P + wQ, P - wQ)
+// Indexing and twiddles are those of the scalar transform (ntt.hpp, k_ntt_pass): forward = Cooley-Tukey (P + wQ, P - wQ)
 // on natural input from the largest distance down, one twiddle w = omega^bitrev(block) per block; inverse = Gentleman-Sande
 // (P + Q, (P - Q) w^-1) from the smallest distance up.  The inverse's factor 2^-p rides in the stored scalar transform.
 template <class KF, bool INV>

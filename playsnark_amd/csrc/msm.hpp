@@ -23,7 +23,7 @@
 // 224 B G2, 16-B aligned, read with dwordx4 loads); scalars 8 x u32 little-endian plain; keys/ranks/sorted as [W][n] u32 so the
 // digit kernel's stores are coalesced across scalars; buckets and partials AoS XYZZ.
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace ps {
 
@@ -36,7 +36,7 @@ struct MsmPlan {
     int SEG;     // buckets per reduction thread
     int sets;    // bucket sets: W, or 1 when the points come with their window table 2^(c w) P (all windows share one set)
     bool table;  // the point pass reads the window table (a plain plan with a single window also has sets == 1)
-    // trees of lane-cooperative additions (qtail.cuh) instead of chains, decided separately for the two halves of the tail:
+    // trees of lane-cooperative additions (qtail.hpp) instead of chains, decided separately for the two halves of the tail:
     bool qtail;   // REDUCTION by rows / columns / bits of the buckets themselves (k_qreduce_*): bucket sets of <= 2^16 buckets in all
     bool hybrid;  // ... else the 8-bucket running sums (k_reduce_l1) and quads behind them; false: the chains of round 2 throughout
     bool shortsum;  // fewer than PS_QTAIL_MAX_ENTRIES digits: short slices, cut buckets summed by quads (k_qfixup), one stream when alone
@@ -967,10 +967,10 @@ __global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restr
 // Heavy buckets (skewed scalars: a witness that is half ones puts n/2 entries into one bucket).  The
 // partial slots of the slices t0..t1 of such a bucket are summed in two levels: the slices are cut into
 // jobs, any workgroup takes any job (strided sums, then a tree), and a last kernel adds up the job results
-// of each bucket -- k_qfixup_heavy_part / k_qfixup_heavy in qtail.cuh, on lane quads.  The dependency chain
+// of each bucket -- k_qfixup_heavy_part / k_qfixup_heavy in qtail.hpp, on lane quads.  The dependency chain
 // is ~2 (s + 6) quad additions whatever the skew (heavy_chunk_of), and a single enormous bucket still uses the chip.
 constexpr u32 HEAVY_CHUNK = 1024;  // (job size of the one-lane kernels of rounds 1-2; k_heavy_jobs keeps it for npb = 0)
-// Slices per job of a heavy bucket that spans `span` slices, for the quad-tree kernels (qtail.cuh; npb = partial sums per block:
+// Slices per job of a heavy bucket that spans `span` slices, for the quad-tree kernels (qtail.hpp; npb = partial sums per block:
 // 64 G1, 32 G2): npb * s with s = ceil(sqrt(span) / npb), so that both levels -- a job's s strided additions and a tree of
 // log2(npb), then the same over the bucket's ~sqrt(span) jobs -- are equally deep whatever the size of the bucket.
 __host__ __device__ inline u32 heavy_chunk_of(u32 span, u32 npb) {
@@ -1012,7 +1012,7 @@ __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs
 }
 
 // (The one-lane kernels that summed a heavy bucket's jobs in rounds 1-2 -- strided chains and an LDS tree per job of 1024
-// slices -- are gone: every plan uses the two levels of quad trees in qtail.cuh, k_qfixup_heavy_part / k_qfixup_heavy.)
+// slices -- are gone: every plan uses the two levels of quad trees in qtail.hpp, k_qfixup_heavy_part / k_qfixup_heavy.)
 
 // ---------------------------------------------------------------------------------------
 // 6. bucket reduction: window sum = sum_{b=0}^{NB-1} (b+1) * B[b]
@@ -1584,4 +1584,4 @@ __global__ void __launch_bounds__(256, 1) k_fixed_base_mul(const Affine<typename
 
 }  // namespace ps
 
-#include "qtail.cuh"
+#include "qtail.hpp"

@@ -1,7 +1,7 @@
 // Radix-2 number-theoretic transforms over the BLS12-381 scalar field Fr (2-adicity 32) and the
 // batched polynomial products built on them.  The reference has no FFT: its Poly.Mul is
 // schoolbook (algebra.go:92-105).  Here the NTT is only a *multiplication engine* -- the QAP
-// lives on the reference's integer domain {1..n} (qap.go:42-55), see quotient.cuh.
+// lives on the reference's integer domain {1..n} (qap.go:42-55), see quotient.hpp.
 //
 // Forward = Cooley-Tukey butterflies (a + w b, a - w b) on natural-order input, bit-reversed
 // output; inverse = Gentleman-Sande butterflies (a + b, (a - b) w^-1) on bit-reversed input,
@@ -10,7 +10,7 @@
 //   * all butterflies of a block share ONE twiddle (w = omega^bitrev(block)), so twiddle traffic
 //     is a broadcast, not a gather;
 //   * the forward transform only ever *adds* a product to a value, so with the lazy Fr
-//     representation (field.cuh) values grow by ~r per stage and need no reduction at all; the
+//     representation (field.hpp) values grow by ~r per stage and need no reduction at all; the
 //     inverse doubles per stage along the all-sums path; the factor is divided out by the last pass
 //     (and by an earlier one only if it would pass 2^16).
 // A transform of 2^p points is cut into ceil(p/10) passes; each pass stages a tile of 2^k rows x
@@ -20,7 +20,7 @@
 #pragma once
 #include <algorithm>
 
-#include "field.cuh"
+#include "field.hpp"
 
 namespace ps {
 
@@ -56,7 +56,7 @@ constexpr int NTT_TILE_LOG = 10;    // 1024 Fr = 40 KB of LDS per workgroup
 // forward transform and 0..k-1 for the inverse.  Column q = (hi, lo) with lo = q mod D; element
 // (t, q) lives at hi*D*2^k + t*D + lo.
 // Element-wise work folded into the first pass's load and the last pass's store of a transform, so the
-// Newton -> monomial levels (quotient.cuh) need no separate prepare / multiply / combine kernels:
+// Newton -> monomial levels (quotient.hpp) need no separate prepare / multiply / combine kernels:
 //   load  NTT_LD_UPPER_HALF   x[node*s + i] = i < s/2 ? src[node*s + s/2 + i] : 0      (s = 2^logs)
 //   store NTT_ST_MUL          out = value * aux[index]
 //   store NTT_ST_COMBINE      dst[node*s + i] = (i < s/2 ? dst[node*s + i] : 0) + value
@@ -78,7 +78,7 @@ struct NttFuse {
     int logs = 0;                 // UPPER_HALF / COMBINE: node size
     u64 cnt = 0;                  // *_PAD / *TAKE: element count
     u64 top = 0;                  // REV_PAD / REV_TAKE: index that maps to 0
-    // A batch of two transforms in one buffer (the two interpolations of Groth16's route, quotient.cuh): element index =
+    // A batch of two transforms in one buffer (the two interpolations of Groth16's route, quotient.hpp): element index =
     // member << batch_log | i.  SCALE_PAD reads member 1 from ld_src2 (cnt and the factors apply per member); TAKE writes
     // member m's first cnt values to st_dst[m << st_member_log | i].  The defaults describe a single transform.
     int batch_log = 63;

@@ -177,7 +177,7 @@ __device__ inline void q_block_tree(Fp* sm, KF& mine, u32 pt, u32 grp) {
 
 // ---- fix-up of the buckets cut by slice boundaries: LPB quads per bucket ----
 // Quad `sub` of bucket g sums the partial slots of the slices t0 + sub, t0 + sub + LPB, ..; a tree over the LPB quads
-// follows.  Buckets that span more than QFIX_HEAVY x LPB slices go to the heavy-bucket kernels (msm.cuh section 5).
+// follows.  Buckets that span more than QFIX_HEAVY x LPB slices go to the heavy-bucket kernels (msm.hpp section 5).
 constexpr u32 QFIX_HEAVY = 16;  // (4: buckets a little above the average went heavy by the thousand -- Groth16 on 2^14 constraints 1.7 -> 2.1 ms)
 template <class KF>
 __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u32 G, int Mplan, u32 T, u32 LPB,

@@ -19,12 +19,12 @@
 //   6. h alone: values of A, B, C on the nodes n+1..2n-1 by one convolution each, h there point-wise,
 //      then steps 3-4 once on a second tree over the shifted nodes     [PHGR13Prove, QAP.Quotient]
 // The element-wise work around the transforms (padding, products with stored transforms, adding halves
-// back) is folded into the first load / last store of the NTT passes (ntt.cuh, NttFuse).
+// back) is folded into the first load / last store of the NTT passes (ntt.hpp, NttFuse).
 // Everything per-n (factorials, tree, z, inverse series) is built once in ps_qap_create.
 #pragma once
 #include <vector>
 
-#include "ntt.cuh"
+#include "ntt.hpp"
 
 namespace ps {
 

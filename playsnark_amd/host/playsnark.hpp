@@ -59,14 +59,29 @@ class Points {
         const size_t wb = group == PS_G1 ? 96 : 192;
         check(ps_points_upload(c.get(), group, affine.data(), affine.size() / wb, PS_FMT_AFFINE, &h_));
     }
+    Points(Points&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
     ~Points() { ps_points_free(h_); }
     Points(const Points&) = delete;
     Points& operator=(const Points&) = delete;
     const ps_points* get() const { return h_; }
     size_t size() const { return ps_points_len(h_); }
     int group() const { return ps_points_group(h_); }
+    // This array read as {x^i P} (Xi, Xi2: nodes = 0; XiT, gsi: nodes = 1) -> {l_j(x) P} on the QAP's nodes, without the
+    // secret point: the one-time conversion of a reference-made key (groth16.go:79-97) onto the prover's fast route.
+    template <class Q>
+    Points ToLagrange(const Q& qap, int nodes) const {
+        ps_points* h = nullptr;
+        check(ps_points_monomial_to_lagrange(ctx_->get(), qap.get(), h_, nodes, &h));
+        return Points(*ctx_, h);
+    }
+    Bytes Download() const {
+        Bytes out(size() * (group() == PS_G1 ? 96 : 192));
+        if (!out.empty()) check(ps_points_download(ctx_->get(), h_, 0, size(), out.data()));
+        return out;
+    }
 
   private:
+    Points(Context& c, ps_points* h) : ctx_(&c), h_(h) {}
     Context* ctx_;
     ps_points* h_ = nullptr;
 };

@@ -1,10 +1,10 @@
-// host_limb_check.cpp -- machine check of the lazy-limb contract of playsnark_amd/csrc/field.cuh / curve.cuh and of the
+// host_limb_check.cpp -- machine check of the lazy-limb contract of playsnark_amd/csrc/field.hpp / curve.hpp and of the
 // host-side pairing arithmetic (pairing_math.inc), compiled FOR THE HOST with
 //     g++ -std=c++17 -O1 -fsanitize=address,undefined -fno-sanitize-recover=all -pthread
 // so that every signed 64-bit column sum, every shift and every array access of the product's field code runs under
 // UBSan / ASan (GPU sanitizers are not available on the pool; the arithmetic is the same source on both sides).
 //
-// The contract (field.cuh): limbs are 28-bit, signed and lazy; "class c" means |limb| < c * 2^28.
+// The contract (field.hpp): limbs are 28-bit, signed and lazy; "class c" means |limb| < c * 2^28.
 //   f_mul(a, b)                 needs class(a) class(b) <= 8
 //   f_mul2sub / f_mul2add       need  class(a) class(b) + class(c) class(d) <= 8
 //   f_mul2add2sub               needs the four class products to add up to <= 8
@@ -21,11 +21,11 @@
 #include <future>
 #include <vector>
 
-#include "../playsnark_amd/csrc/curve.cuh"
+#include "../playsnark_amd/csrc/curve.hpp"
 
 using namespace ps;
 
-// what pairing_math.inc expects from msm.cuh / capi.hip
+// what pairing_math.inc expects from msm.hpp / capi.hip
 template <class F> static bool affine_is_identity(const Affine<F>& p) { return fp_all_zero(p.x) && fp_all_zero(p.y); }
 namespace ps {
 #include "../playsnark_amd/csrc/hostfield.inc"
@@ -175,7 +175,7 @@ static void test_fp_products() {
     std::printf("fp products: %d worst-case class combinations and 3000 random cases ok\n", combos);
 }
 
-// Fr: |value| < 64 r (the storage discipline of field.cuh) bounds the top limb; a class above 7 does not fit an i32 limb
+// Fr: |value| < 64 r (the storage discipline of field.hpp) bounds the top limb; a class above 7 does not fit an i32 limb
 static Fr fr_worst(int cls, int pattern) {
     Fr r;
     for (int i = 0; i < FR_L; i++) {
@@ -344,7 +344,7 @@ static void test_group_law(const char* name) {
 PAIRING_TESTS(test_pairing_dev, pairing_dev, IDENT, IDENT, "device representation")
 PAIRING_TESTS(test_pairing_host, pairing, affine_to_host<Fp>, affine_to_host<Fp2>, "host field")
 
-// hostfield.inc against field.cuh: conversions round-trip, every operation commutes with them, and the group law gives
+// hostfield.inc against field.hpp: conversions round-trip, every operation commutes with them, and the group law gives
 // the same points in both representations
 static void test_host_field() {
     for (int it = 0; it < 2000; it++) {

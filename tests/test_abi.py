@@ -31,7 +31,7 @@ def test_product_does_not_touch_the_oracle():
     pkg = os.path.join(ROOT, "playsnark_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".inc", ".h", ".cpp")) and f != "gen_constants.py":
+            if f.endswith((".py", ".hip", ".hpp", ".inc", ".h", ".cpp")) and f != "gen_constants.py":
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
                 assert not re.search(r'#include\s+"[^"]*oracle', txt), f

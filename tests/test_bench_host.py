@@ -34,7 +34,7 @@ def test_synthetic_r1cs_is_the_oracles_synthetic_circuit():
 def test_quotient_work_counts_match_design():
     bench = _bench()
     nbytes, bfly = bench.quotient_work(1 << 20)
-    assert nbytes == 74 * (1 << 20) * 80            # 74 x 2^20 element-transforms, 2 x 40 B each
+    assert nbytes == 74 * (1 << 20) * 64            # 74 x 2^20 element-transforms, 2 x 32 B each
     assert bfly == 567 * (1 << 20)
 
 

@@ -47,14 +47,14 @@ def test_hot_kernels_do_not_spill(code_object):
     hot = [n for n in notes if re.search(r"k_accumulate|k_reduce_sum|k_ntt_passILb0|k_table_next|k_fixed_base_mul|k_batch_to_affine", n)]
     assert len(hot) >= 9, hot
     for n in hot:
-        # the lane-pair G2 accumulation runs two waves per SIMD on purpose (msm.cuh, PS_G2_ACC_WAVES): 46 spilled registers
+        # the lane-pair G2 accumulation runs two waves per SIMD on purpose (msm.hpp, PS_G2_ACC_WAVES): 46 spilled registers
         limit = 48 if ("k_accumulate" in n and "Fp2s" in n) else 0
         assert int(notes[n]["vgpr_spill_count"]) <= limit, (n, notes[n])
 
 
 def test_tail_kernels_fit_beside_an_accumulation_wave(code_object):
     """The chains of the long sums' tail (fix-up, 8-bucket running sums, pyramid) are capped at 256 registers
-    (msm.cuh, PS_TAIL_WAVES = 2) and pay for it in spills: with sums in flight their waves must fit the half of a SIMD's
+    (msm.hpp, PS_TAIL_WAVES = 2) and pay for it in spills: with sums in flight their waves must fit the half of a SIMD's
     register file that a retiring accumulation wave frees (k_reduce_l1 at 306 registers waited for a whole SIMD to drain:
     G2 sum in flight 8.0 -> 7.3-7.6 ms, PHGR13 at 2^20 29.5 -> 28.7 ms)."""
     notes = kernel_notes(code_object)

@@ -1,5 +1,5 @@
 """CPU: the lazy-limb contract of the product's field / curve / pairing arithmetic, machine-checked.  The same sources the
-GPU kernels are built from (playsnark_amd/csrc/field.cuh, curve.cuh, pairing_math.inc) are compiled for the host with
+GPU kernels are built from (playsnark_amd/csrc/field.hpp, curve.hpp, pairing_math.inc) are compiled for the host with
 AddressSanitizer + UndefinedBehaviorSanitizer (signed 64-bit column sums, shifts, array bounds) and driven with worst-case
 limb-class operands, random lazy operands, bucket-style addition chains, the NTT butterfly sequences and the Miller loop
 (tests/host_limb_check.cpp).  GPU sanitizers are not available on the pool; sanitizers run on the CPU build only.

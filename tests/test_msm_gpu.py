@@ -810,7 +810,7 @@ def test_dense_buckets_do_not_take_the_heavy_path(ps_api, ctx, co, pr, log2n):
                                            (5000, 13, True), (1 << 14, 0, True), (1 << 14, 0, False)])
 def test_tail_of_a_sum_chains_and_trees_give_the_oracle_bytes(ps_api, ctx, co, pr, name, n, wbits, table):
     """The tail of a sum (fix-up of cut buckets + bucket reduction) exists twice: work-efficient chains (long sums) and
-    shallow trees of lane-cooperative additions (short sums, csrc/qtail.cuh).  Both must give the oracle's bytes for
+    shallow trees of lane-cooperative additions (short sums, csrc/qtail.hpp).  Both must give the oracle's bytes for
     Poly.BlindEval (algebra.go:348-359) -- plain plan and window table, both groups, every slice length that changes the
     shape of the fix-up (cut buckets summed by 1, 2, .. 32 quads), uniform and skewed scalars."""
     gid, og = _grp(ps_api, co, name)
@@ -826,7 +826,7 @@ def test_tail_of_a_sum_chains_and_trees_give_the_oracle_bytes(ps_api, ctx, co, p
                [k] * n,                                                     # one bucket per window holds everything
                [int(rng.next() & 1) for _ in range(n)],                     # wire values of a boolean circuit
                [1 if i & 1 else rng.fr() for i in range(n)],                # half ones: ONE heavy bucket among ordinary ones (the
-                                                                            # quad-tree heavy kernels of a short sum, qtail.cuh)
+                                                                            # quad-tree heavy kernels of a short sum, qtail.hpp)
                [0] * n]
     try:
         for vi, sc in enumerate(vectors):

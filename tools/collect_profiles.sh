@@ -29,5 +29,21 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$d"
 done
 python3 tools/rocpd_pmc.py /tmp/pmc_bench_FETCH_SIZE.db /tmp/pmc_bench_WRITE_SIZE.db > "$out/${tag}_pmc_bench_msm_2p20.json"
+# the same two passes for the G2 accumulation (bench.py --group g2 carries their sum as roofline.traffic)
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  d=$(mktemp -d /tmp/pmc.XXXX)
+  rocprofv3 --pmc $ctr -d "$d" -o run -- python3 bench.py --group g2 --no-cpu-baseline --no-extras --steps 3 --warmup 1 --in-flight 1 > /dev/null 2>&1
+  cp "$(find "$d" -name '*.db' | head -1)" "/tmp/pmc_g2_$ctr.db"
+  rm -rf "$d"
+done
+python3 tools/rocpd_pmc.py /tmp/pmc_g2_FETCH_SIZE.db /tmp/pmc_g2_WRITE_SIZE.db > "$out/${tag}_pmc_bench_msm_2p20_g2.json"
 python3 tools/rocpd_pmc.py /tmp/pmc_g16_FETCH_SIZE.db /tmp/pmc_g16_WRITE_SIZE.db > "$out/${tag}_pmc_groth16_2p20.json"
 echo "pmc passes done"
+# round 4: issue / stall counters of the hot kernels, the quotient phase kernel by kernel, the shares of a sharded proof
+tools/sq_pmc.sh "$out/${tag}_sq_counters_bench_one_at_a_time.json" bench
+d=$(mktemp -d /tmp/prof.XXXX)
+MONOMIAL=1 REPS=3 rocprofv3 --kernel-trace -d "$d" -o run -- python3 tools/g16_experiment.py > /dev/null 2>&1
+python3 tools/quotient_breakdown.py "$(find "$d" -name '*.db' | head -1)" > "$out/${tag}_quotient_breakdown.txt"
+rm -rf "$d"
+python3 tools/g16_shares.py > "$out/${tag}_g16_shares.txt" 2>&1
+echo "round-4 extras done"

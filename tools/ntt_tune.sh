@@ -1,5 +1,5 @@
 #!/bin/bash
-# Pass shapes of the register-resident NTT (csrc/ntt.cuh, -DPS_NTT_PASS8: measured, not shipped) against each other.
+# Pass shapes of the register-resident NTT (csrc/ntt.hpp, -DPS_NTT_PASS8: measured, not shipped) against each other.
 # Measurement builds: hipcc ... -DPS_NTT_PASS8 -DPS_NTT_TUNE -o playsnark_amd/libps_tune.so capi.hip; libps_nobf.so adds
 # -DPS_NTT8_SKIP_BF (no butterflies: what the memory side of a pass costs alone).  Per setting: the quotient's time inside Groth16Prove
 # with the reference's key form at 2^20 constraints, and the passes by launch shape.

@@ -25,7 +25,7 @@ rec = {
     "hbm_bytes_per_launch_if_fetch_doubled": (2 * fetch + write) * 1024,
     "algorithmic_bytes_per_launch": 1 << 27,
     "expected_gather_plus_stores": 13 * (1 << 20) * 128 + 1.05 * (1 << 19) * 224 + 2 * 13 * (1 << 20) / 32 * 224 * 0.5,
-    "measured_at": "round 3, commit %s (the kernels of this commit)" % commit,
+    "measured_at": "round %s, commit %s (the kernels of this commit)" % (out_tag.lstrip("r0") or "?", commit),
     "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), KB units, tools/collect_profiles.sh.  The gather reads one "
             "128-byte table row per entry (13.6 M entries = 1.74 GB); FETCH_SIZE reports ~1.1 GB raw -- between the guide's 'half "
             "of a wide coalesced read' and the full count: this access width (7 x 16 B per lane out of a 128-byte row) is "
@@ -35,4 +35,23 @@ rec = {
               "--no-cpu-baseline --no-extras --steps 4 --warmup 1 --in-flight 1`)" % out_tag,
 }
 json.dump(rec, open(os.path.join(root, "profiles", "pmc_accumulate.json"), "w"), indent=1)
+g2_path = os.path.join(src, tag + "_pmc_bench_msm_2p20_g2.json")
+if os.path.exists(g2_path):  # round 4: the G2 accumulation's passes (bench.py --group g2)
+    pmc2 = json.load(open(g2_path))
+    kern2 = [k for k in pmc2["FETCH_SIZE"] if "k_accumulate<ps::Fp2s" in k][0]
+    f2, w2 = pmc2["FETCH_SIZE"][kern2]["avg"], pmc2["WRITE_SIZE"][kern2]["avg"]
+    rec2 = {
+        "kernel": "k_accumulate<Fp2s, false>",
+        "launch": "2^20 G2 points with their window table (c = 20, 13 windows, one set of 2^19 buckets), M = 32, lane pairs",
+        "FETCH_SIZE_KB": f2, "WRITE_SIZE_KB": w2,
+        "hbm_bytes_per_launch": (f2 + w2) * 1024,
+        "hbm_bytes_per_launch_if_fetch_doubled": (2 * f2 + w2) * 1024,
+        "algorithmic_bytes_per_launch": (192 + 32) << 20,
+        "measured_at": "round %s, commit %s (the kernels of this commit)" % (out_tag.lstrip("r0") or "?", commit),
+        "note": "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), KB units; the gather reads one 256-byte table row per entry "
+                "(two HBM lines); the kernel's 46 spilled registers add scratch traffic to both counters.  Access width uncalibrated on "
+                "gfx950, as for the G1 record: the raw sum is reported as `traffic`.",
+        "source": "profiles/%s_pmc_bench_msm_2p20_g2.json (bench.py --group g2 --no-cpu-baseline --no-extras --steps 3 --warmup 1 --in-flight 1)" % out_tag,
+    }
+    json.dump(rec2, open(os.path.join(root, "profiles", "pmc_accumulate_g2.json"), "w"), indent=1)
 print("published", src, "as", out_tag, "at", commit)
