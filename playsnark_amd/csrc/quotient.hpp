@@ -94,16 +94,20 @@ __device__ inline Fr fr_sub_mul_small_div_2p28(const Fr& up, const Fr& coef, u32
 // off = 0 for the QAP domain {1..n}; off = n for the nodes n+1.. of the h-only path.
 // The nodes are small integers, so each step multiplies by a plain c < 2^28 and divides by 2^28 (one
 // Montgomery step, see above) instead of a full field multiplication.  To keep every term at the same
-// scale, d[64b+L] is divided by 2^28 once per step before it enters (lanes L < k in step k), so all terms
+// scale, d[64b+L] enters with the factor 2^(-28 (63 - L)) (lane_scale), so all terms
 // end with the factor 2^(-28*63); `unscale` = 2^(28*63) (Montgomery form) removes it.
 // A batch of conversions (the two interpolations of a small circuit, interpolate2_on_1_to_n): `member64` blocks per member,
 // the nodes start again at off + 1 for every member.
-__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off, Fr unscale, u32 member64) {
+// (Round 4: the scale of d[64b+L] is set ONCE, by a product with lane_scale[L] = 2^(-28 (63 - L)), instead of one Montgomery step
+// per loop trip for the lanes L < k -- a divergent ~45 instructions in 63 of the 64 trips: the kernel was 0.67 ms of the 9.4 ms
+// quotient at 2^20 gates.)
+__global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nblocks64, u64 off, Fr unscale, u32 member64,
+                                                     const Fr* __restrict__ lane_scale) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= nblocks64) return;
     const u64 base = 64ull * wave;
-    Fr mine = d[base + lane];
+    const Fr mine = fr_mul(d[base + lane], lane_scale[lane]);
     Fr coef = fr_zero();
     u32 c = (u32)(off + 64ull * (wave % member64) + 64);  // node of step k = 63
     for (int k = 63; k >= 0; k--) {
@@ -111,7 +115,6 @@ __global__ void __launch_bounds__(256) k_newton_base(Fr* __restrict__ d, u32 nbl
         Fr dk = fr_shfl(mine, k);
         coef = fr_sub_mul_small_div_2p28(up, coef, c);
         if (lane == 0) coef = fr_add(coef, dk);
-        if (lane < k) mine = fr_div_2p28(mine);
         c -= 1;
     }
     d[base + lane] = fr_mul(coef, unscale);
@@ -346,6 +349,7 @@ struct QapTables {
     std::vector<Fr*> zhat_h;     // subproduct tree over the nodes n+1 .. n+np_h
     // work buffers
     Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
+    Fr* newton_scale = nullptr;  // 64: 2^(-28 (63 - L)), the scale lane L's coefficient enters k_newton_base with
     Fr* s4 = nullptr;            // 8np: the two interpolations of Groth16's route as ONE batch of transforms (any n, round 4) ...
     bool batch_h = false;        // ... and, for short transforms only, the three convolutions of the h-values path as a batch of four
     std::vector<void*> owned;
@@ -371,13 +375,14 @@ static inline hipError_t qt_alloc(QapTables& qt, Fr** p, u64 count) {
 // coefficients, in place
 // `members` (a power of two) conversions at once: data and scratch hold members x np elements, every member on the same nodes
 static inline hipError_t newton_to_monomial(const NttTables& tabs, hipStream_t st, u64 np, int lognp, const std::vector<Fr*>& zhat,
-                                            u64 off, Fr* data, Fr* scratch, u64 members = 1) {
+                                            u64 off, Fr* data, Fr* scratch, const Fr* lane_scale, u64 members = 1) {
     Fr unscale = fr_from_u64(1ull << 28);  // 2^(28*63), Montgomery form
     {
         const Fr two28 = unscale;
         for (int i = 1; i < 63; i++) unscale = fr_mul(unscale, two28);
     }
-    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np * members)), dim3(256), 0, st, data, (u32)(np * members / 64), off, unscale, (u32)(np / 64));
+    hipLaunchKernelGGL(k_newton_base, dim3(nblk(np * members)), dim3(256), 0, st, data, (u32)(np * members / 64), off, unscale, (u32)(np / 64),
+                       lane_scale);
     for (int logs = 7; logs <= lognp; logs++) {
         // scratch = NTT(upper halves of the nodes, zero-padded) * zhat ; data = lower halves + INTT(scratch):
         // prepare, multiply and combine ride on the first load / last store of the two transforms
@@ -401,7 +406,7 @@ static inline hipError_t interpolate_on_nodes(const NttTables& tabs, hipStream_t
     NttFuse g;
     g.st = NTT_ST_TAKE; g.st_dst = qt.data; g.cnt = cnt;
     QT_TRY(ntt_conv(tabs, st, qt.t1, 2 * np, lognp + 1, f, g, vhat));
-    return newton_to_monomial(tabs, st, np, lognp, zhat, off, qt.data, qt.scratch);
+    return newton_to_monomial(tabs, st, np, lognp, zhat, off, qt.data, qt.scratch, qt.newton_scale);
 }
 // values y[0..n) = f(1..n)  ->  monomial coefficients of the degree < n interpolant, in qt.data
 static inline hipError_t interpolate_on_1_to_n(const NttTables& tabs, hipStream_t st, const QapTables& qt, const Fr* y) {
@@ -421,7 +426,7 @@ static inline hipError_t interpolate2_on_1_to_n(const NttTables& tabs, hipStream
     g.st = NTT_ST_TAKE; g.st_dst = data; g.cnt = qt.n; g.batch_log = qt.lognp + 1; g.st_member_log = qt.lognp;
     if (qt.n < np) QT_TRY(hipMemsetAsync(data, 0, sizeof(Fr) * 2 * np, st));
     QT_TRY(ntt_conv(tabs, st, t1, 2 * L, qt.lognp + 1, f, g, qt.vhat, L - 1));
-    QT_TRY(newton_to_monomial(tabs, st, np, qt.lognp, qt.zhat, 0, data, scratch, 2));
+    QT_TRY(newton_to_monomial(tabs, st, np, qt.lognp, qt.zhat, 0, data, scratch, qt.newton_scale, 2));
     QT_TRY(hipMemcpyAsync(out0, data, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
     QT_TRY(hipMemcpyAsync(out1, data + np, sizeof(Fr) * qt.n, hipMemcpyDeviceToDevice, st));
     return hipGetLastError();
@@ -548,6 +553,15 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     QT_TRY(qt_alloc(qt, &qt.s4, 8 * np));
     qt.batch_h = 2 * np <= QT_BATCH_MAX_L;
     QT_TRY(qt_alloc(qt, &qt.z, n + 1));
+    {
+        Fr tab[64];
+        const Fr inv28 = fr_inv(fr_from_u64(1ull << 28));
+        tab[63] = fr_one();
+        for (int L = 62; L >= 0; L--) tab[L] = fr_mul(tab[L + 1], inv28);
+        QT_TRY(qt_alloc(qt, &qt.newton_scale, 64));
+        QT_TRY(hipMemcpyAsync(qt.newton_scale, tab, sizeof tab, hipMemcpyHostToDevice, st));
+        QT_TRY(hipStreamSynchronize(st));  // (tab is on this stack frame)
+    }
     QT_TRY(qt_alloc(qt, &qt.ghat, Sh));
     // ---- factorials up to 2np - 1 (host; ps_qap_create computes them on a thread of its own) ----
     {
@@ -607,7 +621,7 @@ static inline hipError_t qap_tables_build(NttTables& tabs, hipStream_t st, QapTa
     } else {  // z is the Newton basis polynomial N_n: convert the unit vector e_n
         QT_TRY(hipMemsetAsync(qt.pa, 0, sizeof(Fr) * np, st));
         hipLaunchKernelGGL(k_set_one, dim3(1), dim3(64), 0, st, qt.pa, n);
-        QT_TRY(newton_to_monomial(tabs, st, np, lg, qt.zhat, 0, qt.pa, qt.pb));
+        QT_TRY(newton_to_monomial(tabs, st, np, lg, qt.zhat, 0, qt.pa, qt.pb, qt.newton_scale));
         QT_TRY(hipMemcpyAsync(qt.z, qt.pa, sizeof(Fr) * (n + 1), hipMemcpyDeviceToDevice, st));
     }
     // ---- g = rev(z)^-1 mod x^(n-1) by Newton iteration ----

@@ -692,6 +692,49 @@ def test_blind_eval_with_host_scalars_is_seam_s1(ps_api, ctx, co, pr, name):
         ps_api.blind_eval_host(ctx, pts, co.pack_fr([1, 2, 3]))
 
 
+def test_view_tables_are_built_once_under_two_racing_threads(ps_api, co, pr):
+    """Two host threads, each with its own context, race into the FIRST sums over views of one shared table-carrying array
+    (the shares of a sharded prover): the view tables are built under the array's lock and published complete; every sum of
+    both threads, over several views, is the oracle's."""
+    import threading
+
+    rng = _rng(pr, 38000)
+    n = 1 << 14
+    ctx0 = ps_api.Context(0)
+    whole = ps_api.Points.from_scalars(ctx0, ps_api.G1, ps_api.Poly.upload(ctx0, [rng.fr() for _ in range(n)])).precompute(16)
+    raw = whole.download()
+    views = [(0, 2048), (2048, 2048), (5000, 1500), (n - 1024, 1024)]
+    scs = {v: [rng.fr() for _ in range(v[1])] for v in views}
+    want = {v: co.G1.to_b(co.G1.msm_pippenger(co.pack_fr(scs[v]), raw[v[0] * 96:(v[0] + v[1]) * 96], v[1], 4)) for v in views}
+    errors, barrier = [], threading.Barrier(2)
+
+    def worker(tid):
+        try:
+            cx = ps_api.Context(0)
+            polys = {v: ps_api.Poly.upload(cx, scs[v]) for v in views}
+            barrier.wait()
+            for rep in range(3):
+                for v in (views if tid == 0 else views[::-1]):
+                    got = polys[v].BlindEval(whole.slice(*v))
+                    assert got == want[v], (tid, rep, v)
+                    assert cx.last_msm_info()["window_table"] == 1 and cx.last_msm_info()["window_bits"] < 16
+            cx.close()
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((tid, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    ctx0.close()
+
+
 def test_window_table_in_the_queue_in_multi_sums_and_rebuilt(ps_api, ctx, co, pr):
     """Tables in ps_msm_launch / ps_msm_finish bursts, in ps_msm_multi (all arrays with tables of one window size: the
     table plan; otherwise the plain plan), with ps_msm_set_window forcing the plain path, and rebuilt for another size."""
