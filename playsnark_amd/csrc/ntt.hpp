@@ -146,6 +146,11 @@ PS_INL void ntt_store_fused(Fr* __restrict__ data, u64 addr, const Fr& v, const 
 // Two butterfly stages per LDS round trip where possible: a thread takes the four rows that differ
 // in row bits m and m+1, so loads, stores, index arithmetic and barriers are halved.  Forward
 // (Cooley-Tukey) walks m = k-1 .. 0, inverse (Gentleman-Sande) m = 0 .. k-1.
+#if defined(PS_NTT_X_NONORM)  // timing experiment only (wrong results): what the carry-save steps behind the forward butterflies cost
+#define PS_NTT_FNORM(x) (x)
+#else
+#define PS_NTT_FNORM(x) fr_norm(x)
+#endif
 template <bool INV>
 __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, const NttTile& g, const Fr* __restrict__ tw, int log_tab) {
     const int p = g.p, logD = g.logD, k = g.k, logCols = g.logCols;
@@ -208,12 +213,12 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                     Fr a1 = fr_add(a, c), c1 = fr_sub(a, c), b1 = fr_add(b, d), d1 = fr_sub(b, d);  // class 2, fresh sums
                     twiddle(i00, logD + m_lo, w);  // m_lo < k-1: never the outermost stage
                     Fr wb = fr_mul(b1, w);
-                    tile[t00 * COLS + col] = fr_norm(fr_add(a1, wb));
-                    tile[t01 * COLS + col] = fr_norm(fr_sub(a1, wb));
+                    tile[t00 * COLS + col] = PS_NTT_FNORM(fr_add(a1, wb));
+                    tile[t01 * COLS + col] = PS_NTT_FNORM(fr_sub(a1, wb));
                     twiddle(i10, logD + m_lo, w);
                     Fr wd = fr_mul(d1, w);
-                    tile[t10 * COLS + col] = fr_norm(fr_add(c1, wd));
-                    tile[t11 * COLS + col] = fr_norm(fr_sub(c1, wd));
+                    tile[t10 * COLS + col] = PS_NTT_FNORM(fr_add(c1, wd));
+                    tile[t11 * COLS + col] = PS_NTT_FNORM(fr_sub(c1, wd));
                 } else {
                     // stage m_lo: (a, b) and (c, d) in neighbouring blocks; stage m_hi: (a', c'), (b', d')
                     twiddle(i00, logD + m_lo, w);  // m_lo < the outermost stage: always a real twiddle
@@ -265,7 +270,9 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
         Fr v = tile[slot];
+#if !defined(PS_NTT_X_NOSCALE)  // (timing experiment only: the inverse's scaling product left out -- wrong results)
         if (INV && scale_log) v = fr_mul(v, sc);
+#endif
         ntt_store_fused(data, addr, v, fz);
     }
     PS_NTT_STAMP(3);
