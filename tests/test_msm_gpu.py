@@ -654,6 +654,18 @@ def test_index_range_views_get_a_window_table_of_their_own(ps_api, ctx, co, pr, 
     assert got == og.to_b(og.msm_pippenger(co.pack_fr(sc_long), raw[og.nb:(n - 1) * og.nb], n - 2, 4))
     vals = [int(rng.next() % 2000) - 1000 for _ in range(cnt)]
     assert ps_api.Poly.from_values(ctx, vals).BlindEval(view) == og.to_b(og.blind_eval_i64(vals, raw[first * og.nb:(first + cnt) * og.nb]))
+    # a view whose table does not fit the context's budget gets none (the plans it had before apply); a later request with room builds it
+    v3 = whole.slice(9000, 3000)
+    sc3 = [rng.fr() for _ in range(3000)]
+    want3 = og.to_b(og.msm_pippenger(co.pack_fr(sc3), raw[9000 * og.nb:12000 * og.nb], 3000, 4))
+    p3 = ps_api.Poly.upload(ctx, sc3)
+    ctx.set_table_budget(4096)
+    try:
+        assert p3.BlindEval(v3) == want3  # (the array's own 16-bit table, or the plain plan where the model finds that cheaper)
+        assert ctx.last_msm_info()["window_table"] == 0 or ctx.last_msm_info()["window_bits"] == 16
+    finally:
+        ctx.set_table_budget(-1)
+    assert p3.BlindEval(v3) == want3 and ctx.last_msm_info()["window_bits"] < 16 and ctx.last_msm_info()["window_table"] == 1
     # tables off for the context: no table of any kind is read; release: the whole array's plain plan
     ctx.set_tables(False)
     try:
