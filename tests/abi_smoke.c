@@ -113,6 +113,23 @@ int main(int argc, char** argv) {
     uint8_t back[192];
     CHECK(ps_point_convert(PS_G2, PS_FMT_COMPRESSED, PS_FMT_AFFINE, get("B_compressed", 96), back) == PS_OK && !memcmp(back, B, 192));
 
+    /* The reference-made key (monomial arrays only) onto the route without interpolation and division, WITHOUT its toxic waste
+     * (groth16.go:13-14): Xi, Xi2 over the nodes 1..n, XiT over n+1..2n-1, converted over the group elements alone -- the shim's
+     * (*HipGroth16).ToLagrange().  The proof bytes do not change. */
+    {
+        ps_points *lxi = NULL, *lxi2 = NULL, *lxit = NULL, *bad_len = NULL;
+        CHECK(ps_points_monomial_to_lagrange(ctx, qap, xi, 0, &lxi) == PS_OK && ps_points_len(lxi) == 4);
+        CHECK(ps_points_monomial_to_lagrange(ctx, qap, xi2, 0, &lxi2) == PS_OK && ps_points_group(lxi2) == PS_G2);
+        CHECK(ps_points_monomial_to_lagrange(ctx, qap, xit, 1, &lxit) == PS_OK && ps_points_len(lxit) == 3);
+        CHECK(ps_points_monomial_to_lagrange(ctx, qap, xit, 0, &bad_len) == PS_ERR_LENGTH && bad_len == NULL);
+        ps_groth16_pk fast = pk;
+        fast.lxi = lxi; fast.lxi2 = lxi2; fast.lxi_t = lxit;
+        uint8_t A2[96], B2[192], C2[96];
+        CHECK(ps_groth16_prove(ctx, &fast, qap, sol, get("r", 32), get("s", 32), A2, B2, C2) == PS_OK);
+        CHECK(!memcmp(A2, A, 96) && !memcmp(B2, B, 192) && !memcmp(C2, C, 96));
+        ps_points_free(lxi); ps_points_free(lxi2); ps_points_free(lxit);
+    }
+
     /* Groth16Verify (groth16.go:214-233): Gamma = gamma * G2 from the fixture's toxic waste */
     ps_scalars* gam = NULL;
     ps_points* gam_pt = NULL;
