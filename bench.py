@@ -347,7 +347,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--slice", type=int, default=0)
     ap.add_argument("--group", choices=["g1", "g2"], default="g1", help="g2 is a side measurement, not the headline metric")
-    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
+    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3, 4], default=4,
                     help="sums kept in flight per GPU (k: step i+k-1 is enqueued before step i is folded)")
     ap.add_argument("--scalars", choices=["uniform", "witness"], default="uniform",
                     help="uniform: 255-bit scalars (the headline); witness: int64 values as the reference's Vector holds "
@@ -643,7 +643,7 @@ def extras(api, ctx, args, mad_peak):
     #3, #5) with the quotient's own roofline.  Not part of `value`."""
     out = {}
 
-    def msm_ms(gid, n, seed, steps, witness=False, in_flight=3):
+    def msm_ms(gid, n, seed, steps, witness=False, in_flight=4):
         a = api.Poly.upload(ctx, uniform_scalars_be32(n, seed).tobytes())
         pts = api.Points.from_scalars(ctx, gid, a)
         if not args.no_table and not args.window:

@@ -48,7 +48,7 @@ typedef struct ps_qap ps_qap;         /* device-resident sparse QAP + per-n tabl
  * "not present", and garbage in a member added by a later revision would be dereferenced.
  *   1  round 1;  2  Lagrange-form key arrays (lxi / lxi2 / lxi_t / lgsi), multi-device entries;
  *   3  ps_msm_info.window_table, ps_msm_set_tail, ps_ctx_set_table_budget, ps_qap_is_valid, ps_microbench_mad;
- *   4  ps_points_monomial_to_lagrange; index-range views build window tables of their own (no struct changed) */
+ *   4  ps_points_monomial_to_lagrange; index-range views build window tables of their own; PS_MSM_QUEUE 3 -> 4 (no struct changed) */
 #define PS_ABI_VERSION 4
 int ps_abi_version(void);
 const char* ps_last_error(void);
@@ -145,11 +145,13 @@ int ps_msm_i64(ps_ctx* ctx, const ps_points* points, const int64_t* scalars, siz
  * ps_msm_finish() waits for the OLDEST pending sum and folds it on the host.  Up to PS_MSM_QUEUE sums
  * may be pending on a context (PS_ERR_ARG beyond that): each runs on its own internal stream and
  * workspace, the accumulations chained in launch order, so a caller that keeps the queue full
- * (launch i+2, then finish i) hides each sum's sort and its latency-bound tail -- bucket fix-up,
- * reduction, host fold -- under its neighbours' accumulations.  The one-call forms (ps_msm, ps_msm_be32,
- * ps_msm_i64, ps_msm_multi, the provers) need an empty queue (PS_ERR_ARG otherwise). */
+ * (launch i+3, then finish i) hides each sum's sort and its latency-bound tail -- bucket fix-up,
+ * reduction, host fold -- under its neighbours' accumulations.  Four is the measured optimum for 2^20-point sums
+ * (2.70 ms per sum with three pending, 2.63 with four, 2.9 with five or six: the tail of the oldest sum is starved by
+ * the accumulations queued behind it).  The one-call forms (ps_msm, ps_msm_be32, ps_msm_i64, ps_msm_multi, the provers)
+ * need an empty queue (PS_ERR_ARG otherwise). */
 #ifndef PS_MSM_QUEUE
-#define PS_MSM_QUEUE 3
+#define PS_MSM_QUEUE 4
 #endif
 int ps_msm_launch(ps_ctx* ctx, const ps_points* points, const ps_scalars* scalars);
 int ps_msm_finish(ps_ctx* ctx, uint8_t* out);

@@ -33,7 +33,7 @@ SYMBOLS = [
 ]
 
 
-PS_MSM_QUEUE = 3  # pending sums per context (include/playsnark_hip.h)
+PS_MSM_QUEUE = 4  # pending sums per context (include/playsnark_hip.h)
 
 
 class MsmInfo(C.Structure):

@@ -104,7 +104,7 @@ struct ps_ctx {
     PendingMsm q[PS_MSM_QUEUE];
     int q_head = 0, q_len = 0;
     bool pending = false;            // q_len > 0
-    ps_ctx *pipe = nullptr, *pipe2 = nullptr, *pipe3 = nullptr;
+    ps_ctx *pipe = nullptr, *pipe2 = nullptr, *pipe3 = nullptr, *pipe4 = nullptr, *pipe5 = nullptr;
     hipEvent_t ev_fork = nullptr;
     ps_ctx* last_chain = nullptr;    // workspace of the sum launched last (its ev_acc_local = accumulation done)
     ps_ctx* last_timed = nullptr;
@@ -284,6 +284,8 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
     if (c->pipe) ps_ctx_destroy(c->pipe);
     if (c->pipe2) ps_ctx_destroy(c->pipe2);
     if (c->pipe3) ps_ctx_destroy(c->pipe3);
+    if (c->pipe4) ps_ctx_destroy(c->pipe4);
+    if (c->pipe5) ps_ctx_destroy(c->pipe5);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_multi) if (e) (void)hipEventDestroy(e);
@@ -1583,9 +1585,10 @@ static int msm_launch_impl(ps_ctx* c, const ps_points* pts, const ps_scalars* sc
     if (c->q_len == PS_MSM_QUEUE) return fail(PS_ERR_ARG, "ps_msm_launch: PS_MSM_QUEUE sums are already pending on this context");
     HIP_TRY(hipSetDevice(c->device));
     // a workspace no pending sum is using: the context itself first
-    ps_ctx** slots[4] = {nullptr, &c->pipe, &c->pipe2, &c->aux};
+    static_assert(PS_MSM_QUEUE >= 1 && PS_MSM_QUEUE <= 6, "workspaces exist for at most six pending sums");
+    ps_ctx** slots[7] = {nullptr, &c->pipe, &c->pipe2, &c->aux, &c->pipe3, &c->pipe4, &c->pipe5};
     ps_ctx* wc = nullptr;
-    for (int w = allow_self ? 0 : 1; w < (allow_self ? PS_MSM_QUEUE : 4) && !wc; w++) {
+    for (int w = allow_self ? 0 : 1; w < (allow_self ? PS_MSM_QUEUE : PS_MSM_QUEUE + 1) && !wc; w++) {
         ps_ctx* cand = w == 0 ? c : *slots[w];
         bool busy = false;
         for (int j = 0; j < c->q_len; j++) busy = busy || (cand && c->q[(c->q_head + j) % PS_MSM_QUEUE].wc == cand);
@@ -1732,7 +1735,7 @@ extern "C" int ps_ctx_set_timing(ps_ctx* c, int enable) {
     if (!c) return fail(PS_ERR_ARG, "ctx is NULL");
     c->timing = enable != 0;
     c->ev_valid = false;
-    for (ps_ctx* w : {c->pipe, c->pipe2})
+    for (ps_ctx* w : {c->pipe, c->pipe2, c->aux, c->pipe3, c->pipe4, c->pipe5})
         if (w) { w->timing = c->timing; w->ev_valid = false; }
     return PS_OK;
 }

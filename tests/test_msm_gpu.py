@@ -282,17 +282,17 @@ def test_two_sums_in_flight_fifo(ps_api, ctx, co, pr):
         jobs.append((gid, pts, dsc, dsc.BlindEval(pts)))
     from playsnark_amd import _lib
 
-    assert _lib.PS_MSM_QUEUE == 3
-    for trio in ((0, 1, 3), (1, 0, 2), (2, 3, 0), (3, 3, 3)):
+    assert _lib.PS_MSM_QUEUE == 4
+    for trio in ((0, 1, 3, 2), (1, 0, 2, 0), (2, 3, 0, 1), (3, 3, 3, 3)):  # PS_MSM_QUEUE sums fill the queue
         for j in trio:
             ps_api.msm_launch(ctx, jobs[j][1], jobs[j][2])
         with pytest.raises(ps_api.PlaysnarkError):  # the queue is full
             ps_api.msm_launch(ctx, jobs[trio[0]][1], jobs[trio[0]][2])
         for j in trio:
             assert ps_api.msm_finish(ctx, jobs[j][0]) == jobs[j][3]
-    # steady-state pipelines of depth 2 and 3: launch ahead, finish the oldest
+    # steady-state pipelines of depth 2, 3 and 4: launch ahead, finish the oldest
     order = [0, 1, 3, 0, 0, 1, 2, 3, 1]
-    for depth in (2, 3):
+    for depth in (2, 3, 4):
         launched = finished = 0
         while finished < len(order):
             while launched < len(order) and launched - finished < depth:
