@@ -27,6 +27,17 @@
 
 namespace ps {
 
+// Wave priority of the sort and tail kernels (s_setprio; 0 = leave it alone).  With sums in flight their waves share SIMDs with two
+// accumulation waves each, and the oldest sum's tail is what the host waits for.
+#ifndef PS_TAIL_PRIO
+#define PS_TAIL_PRIO 0
+#endif
+#if PS_TAIL_PRIO > 0
+#define PS_TAIL_PRIO_HERE __builtin_amdgcn_s_setprio(PS_TAIL_PRIO)
+#else
+#define PS_TAIL_PRIO_HERE do { } while (0)
+#endif
+
 struct MsmPlan {
     int c;       // window bits
     int W;       // windows (digits per scalar)
@@ -469,6 +480,7 @@ constexpr int COUNT_PER_THREAD = 2;  // scalars per thread: 2048 per workgroup, 
 __global__ void __launch_bounds__(DIGITS_THREADS) k_sort_count(const u32* __restrict__ scalars, u32 n, int c, int W, u32 NB,
                                                                DigitConst cadd, int fold_neg, int single_set, u32 ncoarse, int fb,
                                                                u32* __restrict__ codes, u32* __restrict__ coarse_cnt) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 hist[SORT_MAX_COARSE];
     const u32 tid = threadIdx.x;
     hist[tid] = 0;  // DIGITS_THREADS == SORT_MAX_COARSE
@@ -505,6 +517,7 @@ constexpr u32 SORT_TILE = 1u << 14;
 __global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __restrict__ coarse_cnt, u32 ncoarse, u32* __restrict__ coarse_off,
                                                                u32* __restrict__ coarse_cur, u32* __restrict__ offs_total,
                                                                u32* __restrict__ tile_base) {
+    PS_TAIL_PRIO_HERE;
     const u32 tid = threadIdx.x;
     const u32 cnt = tid < ncoarse ? coarse_cnt[tid] : 0u;
     u32 total;
@@ -523,6 +536,7 @@ __global__ void __launch_bounds__(SORT_MAX_COARSE) k_sort_scan(const u32* __rest
 __global__ void __launch_bounds__(DIGITS_THREADS, 8) k_sort_partition(const u32* __restrict__ codes, u32 n, u32 NB, int single_set, int fb,
                                                                    u32* __restrict__ coarse_cur, unsigned short* __restrict__ part_key,
                                                                    u32* __restrict__ part_val) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 hist[SORT_MAX_COARSE], binstart[SORT_MAX_COARSE], gbase[SORT_MAX_COARSE];
     __shared__ u32 wtot[DIGITS_THREADS / 64];
     extern __shared__ __align__(16) unsigned char dg_smem[];
@@ -584,6 +598,7 @@ __global__ void __launch_bounds__(DIGITS_THREADS, 8) k_sort_partition(const u32*
 __global__ void __launch_bounds__(SORT_FINE) k_sort_fine(const unsigned short* __restrict__ part_key, const u32* __restrict__ part_val,
                                                          const u32* __restrict__ coarse_off, u32 G, int fb, u32* __restrict__ offs,
                                                          u32* __restrict__ sorted) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 hist[SORT_FINE];
     __shared__ u32 wtot[SORT_FINE / 64];
     const u32 p = blockIdx.x, tid = threadIdx.x;
@@ -660,6 +675,7 @@ constexpr u32 SORT_TILE_PER_THREAD = SORT_TILE / SORT_FINE;  // 16
 __global__ void __launch_bounds__(SORT_FINE) k_sort_big_count(const unsigned short* __restrict__ part_key, const u32* __restrict__ coarse_off,
                                                               const u32* __restrict__ tile_base, u32 ncoarse, int fb,
                                                               u32* __restrict__ gcnt) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 hist[SORT_FINE];
     const u32 tid = threadIdx.x;
     for (u32 t = blockIdx.x;; t += gridDim.x) {
@@ -681,6 +697,7 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_big_count(const unsigned sho
 // per big bin: offs[] of its buckets, and the same values left in gcnt[] as the scatter's cursors
 __global__ void __launch_bounds__(SORT_FINE) k_sort_big_scan(const u32* __restrict__ coarse_off, u32 G, int fb, u32* __restrict__ gcnt,
                                                              u32* __restrict__ offs) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 wtot[SORT_FINE / 64];
     const u32 p = blockIdx.x, tid = threadIdx.x;
     const u32 lo = coarse_off[p], hi = coarse_off[p + 1];
@@ -699,6 +716,7 @@ __global__ void __launch_bounds__(SORT_FINE) k_sort_big_scan(const u32* __restri
 __global__ void __launch_bounds__(SORT_FINE) k_sort_big_scatter(const unsigned short* __restrict__ part_key, const u32* __restrict__ part_val,
                                                                 const u32* __restrict__ coarse_off, const u32* __restrict__ tile_base,
                                                                 u32 ncoarse, int fb, u32* __restrict__ gcur, u32* __restrict__ sorted) {
+    PS_TAIL_PRIO_HERE;
     __shared__ u32 hist[SORT_FINE];
     const u32 tid = threadIdx.x;
     for (u32 t = blockIdx.x;; t += gridDim.x) {
@@ -939,6 +957,7 @@ __global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_fixup(const u32* __restr
                                                   const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                   Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                   u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
+    PS_TAIL_PRIO_HERE;
     u32 g = logical_tid<KF>();
     if (g >= G) return;
     const int M = eff_slice(offs[G], T, Mplan);
@@ -982,6 +1001,7 @@ __host__ __device__ inline u32 heavy_chunk_of(u32 span, u32 npb) {
 // job_base[h] = number of jobs of the heavy buckets before h; job_base[nheavy] = total.  One workgroup.
 __global__ void __launch_bounds__(256) k_heavy_jobs(const u32* __restrict__ offs, u32 G, int Mplan, u32 T, const u32* __restrict__ heavy_count,
                                                     const u32* __restrict__ heavy_list, u32* __restrict__ job_base, u32 npb) {
+    PS_TAIL_PRIO_HERE;
     const int M = eff_slice(offs[G], T, Mplan);
     __shared__ u32 wsum[4];
     const u32 nheavy = *heavy_count;
@@ -1079,6 +1099,7 @@ template <class KF>
 __global__ void __launch_bounds__(256, PS_TAIL_WAVES) k_reduce_l1(const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                       u32 nseg_total, Xyzz<typename FieldTraits<KF>::Store>* __restrict__ accs,
                                                       Xyzz<typename FieldTraits<KF>::Store>* __restrict__ runs) {
+    PS_TAIL_PRIO_HERE;
     u32 idx = logical_tid<KF>();
     if (idx >= nseg_total) return;
     const Xyzz<typename FieldTraits<KF>::Store>* B = buckets + (size_t)idx * RED_SEG;

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) k_qfixup(const u32* __restrict__ offs, u3
                                                 const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ parts,
                                                 Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                 u32* __restrict__ heavy_count, u32* __restrict__ heavy_list) {
+    PS_TAIL_PRIO_HERE;
     constexpr u32 GL = QTraits<KF>::GL;
     __shared__ Fp sm[256];
     const int M = eff_slice(offs[G], T, Mplan);
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(256) k_qfixup_heavy_part(const u32* __restrict
                                                             const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
                                                             const u32* __restrict__ job_base,
                                                             Xyzz<typename FieldTraits<KF>::Store>* __restrict__ hparts) {
+    PS_TAIL_PRIO_HERE;
     constexpr u32 GL = QTraits<KF>::GL, NPB = 256 / GL;
     __shared__ Fp sm[256];
     const u32 nheavy = *heavy_count;
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__(256) k_qfixup_heavy(const Xyzz<typename FieldT
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buckets,
                                                        const u32* __restrict__ heavy_count, const u32* __restrict__ heavy_list,
                                                        const u32* __restrict__ job_base) {
+    PS_TAIL_PRIO_HERE;
     constexpr u32 GL = QTraits<KF>::GL, NPB = 256 / GL;
     __shared__ Fp sm[256];
     const u32 nheavy = *heavy_count;
@@ -296,6 +299,7 @@ __global__ void __launch_bounds__(512) k_qreduce_rowcol(const Xyzz<typename Fiel
                                                          Xyzz<typename FieldTraits<KF>::Store>* __restrict__ C,
                                                          const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ extra,
                                                          Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R2) {
+    PS_TAIL_PRIO_HERE;
     constexpr u32 GL = QTraits<KF>::GL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fp* sm = reinterpret_cast<Fp*>(smem_raw);
@@ -328,6 +332,7 @@ __global__ void __launch_bounds__(512) k_qreduce_bits(const Xyzz<typename FieldT
                                                        Xyzz<typename FieldTraits<KF>::Store>* __restrict__ out,
                                                        const u32* __restrict__ entries_src, u32* __restrict__ entries_dst,
                                                        const Xyzz<typename FieldTraits<KF>::Store>* __restrict__ R0) {
+    PS_TAIL_PRIO_HERE;
     constexpr u32 GL = QTraits<KF>::GL;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Fp* sm = reinterpret_cast<Fp*>(smem_raw);

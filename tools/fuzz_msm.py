@@ -84,10 +84,11 @@ while time.time() < t_end:
                     print("MISMATCH (multi)", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, tail=tail, seed=seed, case=cases))
                     sys.exit(1)
             else:
-                for pp in (pts, pts_o, pts):
+                burst = [(pts, gid, want), (pts_o, ogid, want_o), (pts, gid, want), (pts_o, ogid, want_o)][:rnd.choice([3, 4])]  # up to PS_MSM_QUEUE pending
+                for pp, _g, _w in burst:
                     api.msm_launch(ctx, pp, poly)
-                got_f = [api.msm_finish(ctx, gg) for gg in (gid, ogid, gid)]
-                if got_f != [want, want_o, want]:
+                got_f = [api.msm_finish(ctx, gg) for _p, gg, _w in burst]
+                if got_f != [w for _p, _g, w in burst]:
                     print("MISMATCH (in flight)", dict(group=group, n=n, dist=dist, mode=mode, c=c, m=m, tail=tail, seed=seed, case=cases))
                     sys.exit(1)
     finally:
