@@ -172,14 +172,15 @@ struct Storage {  // shared device allocation behind slices
 struct ViewTable {
     size_t first, n;  // the index range [first, first + n) of the allocation
     int c, W;         // window bits, rows
-    void* table;      // W rows of n points (row stride n); nullptr: no room when it was asked for (declined_* as for the whole table)
+    std::atomic<void*> table;  // W rows of n points (row stride n); nullptr: no room when it was asked for (declined_* as for the whole
+                               // table) -- a declined record becomes the table when a later request has room: published last, with release
     long long declined_budget;
     size_t declined_free;
 };
 static void storage_free_view_tables(Storage* s) {
     for (auto& slot : s->vtab) {
         ViewTable* v = slot.exchange(nullptr);
-        if (v) { if (v->table) (void)hipFree(v->table); delete v; }
+        if (v) { if (void* t = v->table.load()) (void)hipFree(t); delete v; }
     }
 }
 static void storage_unref(Storage* s) {
@@ -779,7 +780,8 @@ static const ViewTable* view_table_ensure(ps_ctx* c, const ps_points* p) {
     const size_t n = p->n;
     const int wbits = table_window_for(n);
     const ViewTable* have = view_table_find(st, p->first, n, 0);
-    if (have && (have->table || !decline_outdated(c, have->declined_budget, have->declined_free))) return have->table ? have : nullptr;
+    if (have && (have->table.load(std::memory_order_acquire) || !decline_outdated(c, have->declined_budget, have->declined_free)))
+        return have->table.load(std::memory_order_acquire) ? have : nullptr;
     std::lock_guard<std::mutex> lock(st->mu);
     have = view_table_find(st, p->first, n, 0);
     int slot = -1;
@@ -787,7 +789,7 @@ static const ViewTable* view_table_ensure(ps_ctx* c, const ps_points* p) {
         ViewTable* v = st->vtab[i].load(std::memory_order_acquire);
         if (!v) { slot = i; break; }
         if (v == have) {
-            if (v->table) return v;  // another context built it meanwhile
+            if (v->table.load(std::memory_order_acquire)) return v;  // another context built it meanwhile
             if (!decline_outdated(c, v->declined_budget, v->declined_free)) return nullptr;
         }
     }
@@ -798,7 +800,7 @@ static const ViewTable* view_table_ensure(ps_ctx* c, const ps_points* p) {
     auto declined = [&]() -> const ViewTable* {
         if (decl) { decline_record(c, &decl->declined_budget, &decl->declined_free); return nullptr; }
         if (slot < 0) return nullptr;
-        ViewTable* v = new ViewTable{p->first, n, wbits, W, nullptr, 0, 0};
+        ViewTable* v = new ViewTable{p->first, n, wbits, W, {nullptr}, 0, 0};
         decline_record(c, &v->declined_budget, &v->declined_free);
         st->vtab[slot].store(v, std::memory_order_release);
         return nullptr;
@@ -818,11 +820,10 @@ static const ViewTable* view_table_ensure(ps_ctx* c, const ps_points* p) {
     if (decl) {
         // the declined record becomes the table: readers that saw table == nullptr took another plan; publish the pointer last
         decl->c = wbits; decl->W = W;
-        std::atomic_thread_fence(std::memory_order_release);
-        reinterpret_cast<std::atomic<void*>&>(decl->table).store(tab, std::memory_order_release);
+        decl->table.store(tab, std::memory_order_release);
         return decl;
     }
-    ViewTable* v = new ViewTable{p->first, n, wbits, W, tab, 0, 0};
+    ViewTable* v = new ViewTable{p->first, n, wbits, W, {tab}, 0, 0};
     st->vtab[slot].store(v, std::memory_order_release);
     return v;
 }
@@ -1103,7 +1104,7 @@ static bool table_ref(const ps_points* pts, size_t n, int wbits, int W, TableRef
         }
     }
     if (const ViewTable* v = view_table_find(st, pts->first, n, wbits)) {
-        const void* t = reinterpret_cast<const std::atomic<void*>&>(v->table).load(std::memory_order_acquire);
+        const void* t = v->table.load(std::memory_order_acquire);
         if (t && W <= v->W) {
             *out = TableRef{(const char*)t, (u64)v->n};
             return true;

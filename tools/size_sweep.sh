@@ -1,5 +1,5 @@
 #!/bin/bash
-# One MSM per length 2^10 .. 2^23 (G1; 2^10 .. 2^21 for G2), with and without the window table: ms per sum (three in
+# One MSM per length 2^10 .. 2^23 (G1; 2^10 .. 2^21 for G2), with and without the window table: ms per sum (four in
 # flight / alone), window, slice, ns per point -- to spot lengths where a plan choice goes wrong (2^19 once did).
 for g in g1 g2; do
   hi=23; [ $g = g2 ] && hi=21
