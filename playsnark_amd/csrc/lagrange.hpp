@@ -19,8 +19,8 @@
 //     B^T     e_k = <g, N_k>,  T_0 = g,  T_{k+1}[i] = T_k[i+1] - c_k T_k[i],  e_k = T_k[0]   (c_k the node: a small scalar)
 //     C^T     the correlation with (-1)^k / k!, one NTT over points of size 2 np
 //     D^T     L_j = (1 / j!) e_j
-// ~230 cnt scalar multiplications of 255 bits (cnt log^2 cnt / 2 butterflies): seconds at 2^16, a minute or two at 2^20 --
-// once per key.  Every point stays in XYZZ form between stages (no inversions); one batch normalisation at the end gives the
+// ~230 cnt scalar multiplications of 255 bits (cnt log^2 cnt / 2 butterflies; each a GLV split over fixed signed windows,
+// ec_mul_glv below): seconds at 2^16, under a minute at 2^20 -- once per key.  Every point stays in XYZZ form between stages (no inversions); one batch normalisation at the end gives the
 // same canonical affine bytes ps_groth16_setup emits for l_j(x) P (tests/test_prover_gpu.py).
 #pragma once
 #include "msm.hpp"
@@ -64,11 +64,118 @@ __device__ inline Xyzz<KF> ec_mul_words(const Xyzz<KF>& p, const u32* k) {
     }
     return acc;
 }
+
+// ---- full-width scalars: GLV split + fixed signed windows ----
+// The lanes of a wave hold different scalars, so a double-and-add loop pays its addition on every bit (some lane always has
+// the bit set): 255 (dbl + add).  Instead: k = k1 + k2 lambda with k2 = floor(k / lambda), lambda = z^2 - 1 (both halves
+// below 2^128, since lambda^2 + lambda + 1 = r), lambda P = phi(P) = (beta x, y) on the subgroup of order r -- the points of
+// a key are in it; for any other point the result is NOT k P -- and both halves in signed radix-16 digits taken from k' = k
+// + 0x88..8 (digit_i = nibble_i(k') - 8: independent of each other, like the MSM's digits), over ONE table {1..8} P: 33
+// rounds of 4 dbl + 2 add + one product by beta, the same schedule on every lane.  ~2 200 field products instead of ~5 900.
+// (Constants: gen_constants.py, derived and checked in tools/glv_constants.py.)
+PS_HD constexpr i32 fp_glv_beta28(int g2, int i) {
+    constexpr i32 b1[FP_L] = PS_FP28_GLV_BETA_G1;
+    constexpr i32 b2[FP_L] = PS_FP28_GLV_BETA_G2;
+    return g2 ? b2[i] : b1[i];
+}
+template <class KF> struct GlvPhi;
+template <> struct GlvPhi<Fp> {
+    PS_INL static void apply(Xyzz<Fp>& q) {
+        Fp b;
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) b.l[i] = fp_glv_beta28(0, i);
+        q.x = f_mul(q.x, b);
+    }
+};
+template <> struct GlvPhi<Fp2s> {
+    PS_INL static void apply(Xyzz<Fp2s>& q) {  // beta is in Fp: each lane of the pair scales its own component
+        Fp b;
+#pragma unroll
+        for (int i = 0; i < FP_L; i++) b.l[i] = fp_glv_beta28(1, i);
+        q.x = Fp2s{f_mul(q.x.v, b)};
+    }
+};
+// k (8 words, < r) -> q = floor(k / lambda), rem = k mod lambda (4 words each) by binary long division: ~4 000 integer
+// instructions, 0.5 % of the multiplication they steer
+__device__ inline void glv_split(const u32* k, u32* rem, u32* q) {
+    constexpr u32 lam[4] = PS_GLV_LAMBDA;
+    u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+    q[0] = q[1] = q[2] = q[3] = 0;
+    u32 qov = 0;  // (bits of the quotient above 2^128: none for k < r; kept so that a wrong input cannot pass unnoticed)
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+        r4 = (r4 << 1) | (r3 >> 31);
+        r3 = (r3 << 1) | (r2 >> 31);
+        r2 = (r2 << 1) | (r1 >> 31);
+        r1 = (r1 << 1) | (r0 >> 31);
+        r0 = (r0 << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
+        // rem >= lambda ?
+        const u64 d0 = (u64)r0 - lam[0], d1 = (u64)r1 - lam[1] - ((d0 >> 32) & 1), d2 = (u64)r2 - lam[2] - ((d1 >> 32) & 1),
+                  d3 = (u64)r3 - lam[3] - ((d2 >> 32) & 1), d4 = (u64)r4 - ((d3 >> 32) & 1);
+        const bool ge = !((d4 >> 32) & 1);
+        if (ge) { r0 = (u32)d0; r1 = (u32)d1; r2 = (u32)d2; r3 = (u32)d3; r4 = (u32)d4; }
+        if (bit >= 128) qov |= ge ? 1u : 0u;
+        else if (ge) q[bit >> 5] |= 1u << (bit & 31);
+    }
+    rem[0] = r0; rem[1] = r1; rem[2] = r2; rem[3] = r3;
+    if (qov) { q[0] = q[1] = q[2] = q[3] = 0xffffffffu; }  // unreachable for k < r
+}
+// w[0..4] = v[0..3] + 0x8888...8 (32 nibbles): digit i of v in [-8, 7] is nibble i of w minus 8, digit 32 = w[4] (0 or 1)
+__device__ inline void glv_bias(const u32* v, u32* w) {
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        c += (u64)v[i] + 0x88888888ull;
+        w[i] = (u32)c;
+        c >>= 32;
+    }
+    w[4] = (u32)c;
+}
+template <class KF>
+__device__ inline void glv_add_digit(Xyzz<KF>& acc, const Xyzz<KF>* T, int d, bool phi) {
+    if (d == 0) return;
+    Xyzz<KF> t = T[(d < 0 ? -d : d) - 1];
+    if (d < 0) t.y = f_neg(t.y);
+    if (phi) GlvPhi<KF>::apply(t);
+    xyzz_add<KF>(acc, t);
+}
+template <class KF>
+__device__ inline Xyzz<KF> ec_mul_glv(const Xyzz<KF>& p, const u32* k) {
+    if (xyzz_is_identity(p)) return xyzz_identity<KF>();
+    u32 k1[4], k2[4], w1[5], w2[5];
+    glv_split(k, k1, k2);
+    glv_bias(k1, w1);
+    glv_bias(k2, w2);
+    Xyzz<KF> T[8];  // j P, j = 1..8 (private memory: 8 x 224 bytes per lane)
+    T[0] = p;
+    T[1] = xyzz_dbl<KF>(p);
+    T[2] = T[1]; xyzz_add<KF>(T[2], p);
+    T[3] = xyzz_dbl<KF>(T[1]);
+    T[4] = T[3]; xyzz_add<KF>(T[4], p);
+    T[5] = xyzz_dbl<KF>(T[2]);
+    T[6] = T[5]; xyzz_add<KF>(T[6], p);
+    T[7] = xyzz_dbl<KF>(T[3]);
+    Xyzz<KF> acc = xyzz_identity<KF>();
+    glv_add_digit<KF>(acc, T, (int)w1[4], false);  // the top digits: 0 or 1
+    glv_add_digit<KF>(acc, T, (int)w2[4], true);
+#pragma unroll 1
+    for (int i = 31; i >= 0; i--) {
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) acc = xyzz_dbl<KF>(acc);
+        glv_add_digit<KF>(acc, T, (int)((w1[i >> 3] >> ((i & 7) * 4)) & 15u) - 8, false);
+        glv_add_digit<KF>(acc, T, (int)((w2[i >> 3] >> ((i & 7) * 4)) & 15u) - 8, true);
+    }
+    return acc;
+}
 template <class KF>
 __device__ inline Xyzz<KF> ec_mul_fr(const Xyzz<KF>& p, const Fr& s_mont) {
     u32 k[8];
     fr_to_words8(k, fr_from_mont(s_mont));
+#if defined(PS_EC_MUL_PLAIN)  // the double-and-add loop this replaced (A/B and cross-check builds)
     return ec_mul_words<KF>(p, k);
+#else
+    return ec_mul_glv<KF>(p, k);
+#endif
 }
 
 // One stage of the NTT over points, in place: `total` points = a batch of transforms of 2^p, half-distance 2^logh.
