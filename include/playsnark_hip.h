@@ -327,10 +327,11 @@ void ps_phgr13_crs_free(ps_phgr13_crs* crs); /* frees the 14 arrays */
  * takes 18).  ps_groth16_setup emits both forms but needs the toxic waste, which "must be delete[d] after a trusted setup"
  * (groth16.go:13-14).  This is the one-time conversion of an array {x^i P}, i < cnt, into {l_j(x) P}, j < cnt, over the
  * group elements alone (the transposed interpolation of csrc/lagrange.hpp: ~230 cnt scalar multiplications of points; seconds
- * at 2^16 gates, minutes at 2^20).  nodes = 0: the QAP domain 1..n, cnt = n (Xi -> lxi, Xi2 -> lxi2);
+ * at 2^16 gates, under a minute at 2^20).  nodes = 0: the QAP domain 1..n, cnt = n (Xi -> lxi, Xi2 -> lxi2);
  * nodes = 1: the nodes n+1..2n-1, cnt = n-1 (XiT -> lxi_t, gsi -> lgsi).  Either group.  The result is byte-identical to the
  * array ps_groth16_setup / ps_phgr13_setup emit from the toxic waste; the caller frees it.  PS_ERR_LENGTH when the array is
- * not exactly cnt points long. */
+ * not exactly cnt points long.  The points must lie in the subgroup of order r, as the points of a key do (the scalar
+ * multiplications split their scalars with the curve's endomorphism, which acts as a scalar only there). */
 int ps_points_monomial_to_lagrange(ps_ctx* ctx, const ps_qap* q, const ps_points* mono, int nodes, ps_points** out);
 
 /* ---- verifiers (host-side ate pairing; the IO commitments go through the GPU MSM) ---- */

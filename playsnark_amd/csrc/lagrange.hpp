@@ -131,13 +131,22 @@ __device__ inline void glv_bias(const u32* v, u32* w) {
     }
     w[4] = (u32)c;
 }
+// (forced inline: the out-of-line xyzz_add / xyzz_dbl pass their 224-byte operands through scratch memory -- 2^18 points: 2.41 ->
+// 1.86 s G1, 6.70 -> 5.71 s G2)
+#if defined(PS_GLV_OUTLINE)
+#define PS_GLV_ADD(a, t) xyzz_add<KF>(a, t)
+#define PS_GLV_DBL(a) xyzz_dbl<KF>(a)
+#else
+#define PS_GLV_ADD(a, t) xyzz_add_inl<KF>(a, t)
+#define PS_GLV_DBL(a) xyzz_dbl_inl<KF>(a)
+#endif
 template <class KF>
 __device__ inline void glv_add_digit(Xyzz<KF>& acc, const Xyzz<KF>* T, int d, bool phi) {
     if (d == 0) return;
     Xyzz<KF> t = T[(d < 0 ? -d : d) - 1];
     if (d < 0) t.y = f_neg(t.y);
     if (phi) GlvPhi<KF>::apply(t);
-    xyzz_add<KF>(acc, t);
+    PS_GLV_ADD(acc, t);
 }
 template <class KF>
 __device__ inline Xyzz<KF> ec_mul_glv(const Xyzz<KF>& p, const u32* k) {
@@ -161,7 +170,7 @@ __device__ inline Xyzz<KF> ec_mul_glv(const Xyzz<KF>& p, const u32* k) {
 #pragma unroll 1
     for (int i = 31; i >= 0; i--) {
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) acc = xyzz_dbl<KF>(acc);
+        for (int j = 0; j < 4; j++) acc = PS_GLV_DBL(acc);
         glv_add_digit<KF>(acc, T, (int)((w1[i >> 3] >> ((i & 7) * 4)) & 15u) - 8, false);
         glv_add_digit<KF>(acc, T, (int)((w2[i >> 3] >> ((i & 7) * 4)) & 15u) - 8, true);
     }
@@ -178,12 +187,22 @@ __device__ inline Xyzz<KF> ec_mul_fr(const Xyzz<KF>& p, const Fr& s_mont) {
 #endif
 }
 
+// Waves per SIMD of the two kernels that multiply points by full-width scalars (a lone wave issues a dependent multiply-add
+// every other slot).
+#ifndef PS_EC_WAVES_G1
+#define PS_EC_WAVES_G1 2
+#endif
+#ifndef PS_EC_WAVES_G2
+#define PS_EC_WAVES_G2 1
+#endif
+#define PS_EC_WAVES(KF) (FieldTraits<KF>::LANES == 1 ? PS_EC_WAVES_G1 : PS_EC_WAVES_G2)
+
 // One stage of the NTT over points, in place: `total` points = a batch of transforms of 2^p, half-distance 2^logh.
 // Indexing and twiddles are those of the scalar transform (ntt.hpp, k_ntt_pass): forward = Cooley-Tukey (P + wQ, P - wQ)
 // on natural input from the largest distance down, one twiddle w = omega^bitrev(block) per block; inverse = Gentleman-Sande
 // (P + Q, (P - Q) w^-1) from the smallest distance up.  The inverse's factor 2^-p rides in the stored scalar transform.
 template <class KF, bool INV>
-__global__ void __launch_bounds__(256, 1) k_ec_ntt_stage(Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buf, u32 total, int p, int logh,
+__global__ void __launch_bounds__(256, PS_EC_WAVES(KF)) k_ec_ntt_stage(Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buf, u32 total, int p, int logh,
                                                          const Fr* __restrict__ tw, int log_tab) {
     const u32 bf = logical_tid<KF>();
     if (bf >= total / 2) return;
@@ -216,7 +235,7 @@ __global__ void __launch_bounds__(256, 1) k_ec_ntt_stage(Xyzz<typename FieldTrai
 
 // buf[i] = scal[i & mask] * buf[i], i < total   (scalars in Montgomery form)
 template <class KF>
-__global__ void __launch_bounds__(256, 1) k_ec_scale(Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buf, u32 total,
+__global__ void __launch_bounds__(256, PS_EC_WAVES(KF)) k_ec_scale(Xyzz<typename FieldTraits<KF>::Store>* __restrict__ buf, u32 total,
                                                      const Fr* __restrict__ scal, u64 mask) {
     const u32 i = logical_tid<KF>();
     if (i >= total) return;

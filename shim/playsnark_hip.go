@@ -383,7 +383,7 @@ func NewHipGroth16(tr Groth16Setup, q *HipQAP) *HipGroth16 {
 // ToLagrange puts a key made by the reference's NewGroth16TrustedSetup (monomial arrays only) onto the prover's fast route
 // WITHOUT the toxic waste, which "must be delete[d] after a trusted setup" (groth16.go:13-14): Xi, Xi2 and XiT are converted
 // on the GPU into l_j(x) G1, l_j(x) G2 and lambda_k(x) t(x)/delta G1 over the group elements alone
-// (ps_points_monomial_to_lagrange: a transposed interpolation, seconds at 2^16 gates, minutes at 2^20 -- once per key).
+// (ps_points_monomial_to_lagrange: a transposed interpolation, seconds at 2^16 gates, under a minute at 2^20 -- once per key).
 // Afterwards Groth16ProveHIP needs no interpolation and no division; the proof bytes do not change.
 func (hs *HipGroth16) ToLagrange() {
 	if hs.pk.lxi != nil {
