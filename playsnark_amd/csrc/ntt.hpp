@@ -521,6 +521,19 @@ static inline hipError_t ntt_tables_ensure(NttTables& t, int log_size, hipStream
     return hipGetLastError();
 }
 
+#if defined(PS_NTT_TUNE)
+// tiles beyond the default 64 KB of dynamic LDS (PS_NTT_TILE=11: 80 KB)
+static inline hipError_t ntt_tune_raise_lds() {
+    static bool raised = false;
+    if (raised) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_mid), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = e == hipSuccess;
+    return e;
+}
+#endif
+
 // `total` = batch * 2^p elements, contiguous.  Forward: natural -> bit-reversed (per block).
 template <bool INV>
 static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p, const NttFuse& fuse = NttFuse()) {
@@ -534,6 +547,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
 #if defined(PS_NTT_TUNE)  // measurement builds: pass shapes from the environment (tools/ntt_tune.sh)
     if (const char* e = getenv("PS_NTT_MAXK")) max_k = atoi(e);
     if (const char* e = getenv("PS_NTT_TILE")) tile_log = atoi(e);
+    if (ntt_tune_raise_lds() != hipSuccess) return hipErrorInvalidValue;
 #endif
     int npass = p <= tile_log ? 1 : (p + max_k - 1) / max_k;
     // stage groups of nearly equal size; the forward walks them from the top, the inverse from the bottom
@@ -544,6 +558,12 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
     {
         int left = p;
         for (int i = 0; i < npass; i++) { ks[i] = (left + (npass - i) - 1) / (npass - i); left -= ks[i]; }
+#if defined(PS_NTT_TUNE)
+        if (getenv("PS_NTT_SPLIT")) {  // the odd stage goes to the pass on contiguous data (the forward's last, the inverse's first)
+            left = p;
+            for (int i = 0; i < npass; i++) { const int j = INV ? npass - 1 - i : i; ks[j] = left / (npass - i); left -= ks[j]; }
+        }
+#endif
 #if defined(PS_NTT_PASS8)
         const int k0 = p - 6 * (npass - 1);
         // the long pass is the one that runs on contiguous data (logD = 0: the inverse's first, the forward's last); the strided
@@ -652,12 +672,23 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
                                   const Fr* aux, u64 aux_mask = ~0ull) {
     if (p == 0 || p > tb.log_tab || st_fuse.st == NTT_ST_MUL || ld_fuse.st != NTT_ST_PLAIN || st_fuse.ld != NTT_LD_PLAIN) return hipErrorInvalidValue;
     const int log_total = ilog2_ceil(total);
-    const int max_k = NTT_MAX_K, tile_log = NTT_TILE_LOG;
+    int max_k = NTT_MAX_K, tile_log = NTT_TILE_LOG;
+#if defined(PS_NTT_TUNE)  // measurement builds: pass shapes from the environment, as in ntt_run
+    if (const char* e = getenv("PS_NTT_MAXK")) max_k = atoi(e);
+    if (const char* e = getenv("PS_NTT_TILE")) tile_log = atoi(e);
+    if (ntt_tune_raise_lds() != hipSuccess) return hipErrorInvalidValue;
+#endif
     const int npass = p <= tile_log ? 1 : (p + max_k - 1) / max_k;
     int ks[8];  // forward order (from the top); the inverse walks the same groups back
     {
         int left = p;
         for (int i = 0; i < npass; i++) { ks[i] = (left + (npass - i) - 1) / (npass - i); left -= ks[i]; }
+#if defined(PS_NTT_TUNE)
+        if (getenv("PS_NTT_SPLIT")) {
+            left = p;
+            for (int i = 0; i < npass; i++) { ks[i] = left / (npass - i); left -= ks[i]; }
+        }
+#endif
     }
     auto shape = [&](int k, int& logCols, unsigned& grid, size_t& smem, unsigned& threads) {
         logCols = tile_log - k;
