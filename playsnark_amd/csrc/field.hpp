@@ -888,12 +888,19 @@ PS_INL Fr fr_mul(const Fr& a, const Fr& b) {
     Fr r;
     i32 m[FR_L];
     i64 acc = 0;
+    // The top limb of r is 7: left as a literal the compiler multiplies by it with a v_mul_lo_u32 and adds the product with a
+    // 64-bit add (two quarter-rate instructions) where a multiply-add does both -- so it is handed over as an opaque scalar.
+    i32 mod_top = fr_mod28(FR_L - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(mod_top));
+#endif
+    auto modl = [&](int idx) -> i64 { return idx == FR_L - 1 ? (i64)mod_top : (i64)fr_mod28(idx); };
 #pragma unroll
     for (int k = 0; k < FR_L; k++) {
 #pragma unroll
         for (int i = 0; i <= k; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (i64)m[i] * (i64)fr_mod28(k - i);
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * modl(k - i);
         // r = 1 mod 2^28 (two-adicity 32), so -r^-1 = -1 mod 2^28 and the Montgomery digit is a negation,
         // not a (quarter-rate) v_mul_lo_u32
         static_assert(FR_INV28 == FP_MASK, "m = -acc mod 2^28 needs r = 1 mod 2^28");
@@ -906,7 +913,7 @@ PS_INL Fr fr_mul(const Fr& a, const Fr& b) {
 #pragma unroll
         for (int i = k - FR_L + 1; i < FR_L; i++) acc += (i64)a.l[i] * (i64)b.l[k - i];
 #pragma unroll
-        for (int i = k - FR_L + 1; i < FR_L; i++) acc += (i64)m[i] * (i64)fr_mod28(k - i);
+        for (int i = k - FR_L + 1; i < FR_L; i++) acc += (i64)m[i] * modl(k - i);
         r.l[k - FR_L] = (i32)((u32)acc & FP_MASK);
         acc >>= 28;
     }
