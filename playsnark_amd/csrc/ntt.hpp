@@ -151,6 +151,14 @@ PS_INL void ntt_store_fused(Fr* __restrict__ data, u64 addr, const Fr& v, const 
 #else
 #define PS_NTT_FNORM(x) fr_norm(x)
 #endif
+// LDS slot of tile element i.  An element is 10 dwords, so butterfly partners 4, 8, 16, 32 elements apart fall into the same
+// banks 2-, 4-, 8-, 16-way (SQ_LDS_BANK_CONFLICT: 70 % of the LDS-active cycles of k_ntt_mid); XOR-ing the low five bits of
+// the index with the next five spreads every such stride over different banks and keeps runs of consecutive elements intact.
+#if defined(PS_NTT_NO_SWIZZLE)
+#define PS_NTT_SW(i) (i)
+#else
+#define PS_NTT_SW(i) ((i) ^ (((i) >> 5) & 31u))
+#endif
 template <bool INV>
 __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, const NttTile& g, const Fr* __restrict__ tw, int log_tab) {
     const int p = g.p, logD = g.logD, k = g.k, logCols = g.logCols;
@@ -168,7 +176,11 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
         const int M = p - 1 - logh;  // this stage has 2^M blocks per transform
         if (M <= 0) return false;    // the single block of the outermost stage: w = 1
         const u32 blk = (u32)((i & smask) >> (logh + 1));
+#if defined(PS_NTT_X_NEARTW)  // (timing experiment only: every twiddle from the same two cache lines -- wrong results)
+        w = tw[blk & 1u];
+#else
         w = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
+#endif
         return true;
     };
     const u32 nbf = (rows >> 1) << logCols, nq = (rows >> 2) << logCols;
@@ -184,16 +196,16 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
             for (u32 bf = threadIdx.x; bf < nbf; bf += blockDim.x) {
                 u32 col = bf & (COLS - 1), r = bf >> logCols;
                 u32 t0 = ((r >> m) << (m + 1)) | (r & mmask), t1 = t0 | (1u << m);
-                Fr a = tile[t0 * COLS + col], b = tile[t1 * COLS + col], w;
+                Fr a = tile[PS_NTT_SW(t0 * COLS + col)], b = tile[PS_NTT_SW(t1 * COLS + col)], w;
                 const bool has_w = twiddle(gidx(t0, col), logh, w);
                 if (!INV) {
                     Fr wb = has_w ? fr_mul(b, w) : b;
-                    tile[t0 * COLS + col] = fr_norm(fr_add(a, wb));
-                    tile[t1 * COLS + col] = fr_norm(fr_sub(a, wb));
+                    tile[PS_NTT_SW(t0 * COLS + col)] = fr_norm(fr_add(a, wb));
+                    tile[PS_NTT_SW(t1 * COLS + col)] = fr_norm(fr_sub(a, wb));
                 } else {
-                    tile[t0 * COLS + col] = fr_norm(fr_add(a, b));
+                    tile[PS_NTT_SW(t0 * COLS + col)] = fr_norm(fr_add(a, b));
                     Fr d = fr_norm(fr_sub(a, b));
-                    tile[t1 * COLS + col] = has_w ? fr_mul(d, w) : d;
+                    tile[PS_NTT_SW(t1 * COLS + col)] = has_w ? fr_mul(d, w) : d;
                 }
             }
             done_st += 1;
@@ -204,7 +216,7 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                 u32 col = qd & (COLS - 1), r = qd >> logCols;
                 u32 t00 = ((r >> m_lo) << (m_lo + 2)) | (r & lowmask);
                 u32 t01 = t00 | (1u << m_lo), t10 = t00 | (1u << m_hi), t11 = t10 | (1u << m_lo);
-                Fr a = tile[t00 * COLS + col], b = tile[t01 * COLS + col], c = tile[t10 * COLS + col], d = tile[t11 * COLS + col];
+                Fr a = tile[PS_NTT_SW(t00 * COLS + col)], b = tile[PS_NTT_SW(t01 * COLS + col)], c = tile[PS_NTT_SW(t10 * COLS + col)], d = tile[PS_NTT_SW(t11 * COLS + col)];
                 const u64 i00 = gidx(t00, col), i10 = gidx(t10, col);
                 Fr w;
                 if (!INV) {
@@ -213,12 +225,12 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                     Fr a1 = fr_add(a, c), c1 = fr_sub(a, c), b1 = fr_add(b, d), d1 = fr_sub(b, d);  // class 2, fresh sums
                     twiddle(i00, logD + m_lo, w);  // m_lo < k-1: never the outermost stage
                     Fr wb = fr_mul(b1, w);
-                    tile[t00 * COLS + col] = PS_NTT_FNORM(fr_add(a1, wb));
-                    tile[t01 * COLS + col] = PS_NTT_FNORM(fr_sub(a1, wb));
+                    tile[PS_NTT_SW(t00 * COLS + col)] = PS_NTT_FNORM(fr_add(a1, wb));
+                    tile[PS_NTT_SW(t01 * COLS + col)] = PS_NTT_FNORM(fr_sub(a1, wb));
                     twiddle(i10, logD + m_lo, w);
                     Fr wd = fr_mul(d1, w);
-                    tile[t10 * COLS + col] = PS_NTT_FNORM(fr_add(c1, wd));
-                    tile[t11 * COLS + col] = PS_NTT_FNORM(fr_sub(c1, wd));
+                    tile[PS_NTT_SW(t10 * COLS + col)] = PS_NTT_FNORM(fr_add(c1, wd));
+                    tile[PS_NTT_SW(t11 * COLS + col)] = PS_NTT_FNORM(fr_sub(c1, wd));
                 } else {
                     // stage m_lo: (a, b) and (c, d) in neighbouring blocks; stage m_hi: (a', c'), (b', d')
                     twiddle(i00, logD + m_lo, w);  // m_lo < the outermost stage: always a real twiddle
@@ -226,11 +238,11 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                     twiddle(i10, logD + m_lo, w);
                     Fr c1 = fr_add(c, d), d1 = fr_mul(fr_norm(fr_sub(c, d)), w);
                     const bool has_w = twiddle(i00, logD + m_hi, w);
-                    tile[t00 * COLS + col] = fr_norm(fr_add(a1, c1));
-                    tile[t01 * COLS + col] = fr_norm(fr_add(b1, d1));
+                    tile[PS_NTT_SW(t00 * COLS + col)] = fr_norm(fr_add(a1, c1));
+                    tile[PS_NTT_SW(t01 * COLS + col)] = fr_norm(fr_add(b1, d1));
                     Fr e = fr_norm(fr_sub(a1, c1)), f = fr_norm(fr_sub(b1, d1));
-                    tile[t10 * COLS + col] = has_w ? fr_mul(e, w) : e;
-                    tile[t11 * COLS + col] = has_w ? fr_mul(f, w) : f;
+                    tile[PS_NTT_SW(t10 * COLS + col)] = has_w ? fr_mul(e, w) : e;
+                    tile[PS_NTT_SW(t11 * COLS + col)] = has_w ? fr_mul(f, w) : f;
                 }
             }
             done_st += 2;
@@ -251,7 +263,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        tile[slot] = ntt_load_fused(data, addr, fz);
+        tile[PS_NTT_SW(slot)] = ntt_load_fused(data, addr, fz);
     }
     __syncthreads();
     PS_NTT_STAMP(1);
@@ -269,7 +281,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        Fr v = tile[slot];
+        Fr v = tile[PS_NTT_SW(slot)];
 #if !defined(PS_NTT_X_NOSCALE)  // (timing experiment only: the inverse's scaling product left out -- wrong results)
         if (INV && scale_log) v = fr_mul(v, sc);
 #endif
@@ -296,7 +308,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_mid(Fr* __restrict__ data, int p
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        tile[slot] = ntt_load_fused(data, addr, fl);
+        tile[PS_NTT_SW(slot)] = ntt_load_fused(data, addr, fl);
     }
     __syncthreads();
     ntt_tile_stages<false>(tile, g, tw_fwd, log_tab);
@@ -304,7 +316,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_mid(Fr* __restrict__ data, int p
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        tile[slot] = fr_mul(tile[slot], aux[addr & aux_mask]);
+        tile[PS_NTT_SW(slot)] = fr_mul(tile[PS_NTT_SW(slot)], aux[addr & aux_mask]);
     }
     __syncthreads();
     ntt_tile_stages<true>(tile, g, tw_inv, log_tab);
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_mid(Fr* __restrict__ data, int p
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        Fr v = tile[slot];
+        Fr v = tile[PS_NTT_SW(slot)];
         if (scale_log) v = fr_mul(v, sc);
         ntt_store_fused(data, addr, v, fs);
     }
