@@ -262,6 +262,44 @@ def test_monomial_key_to_lagrange_form_at_2pow16(ps_api, ctx, co, pr):
     assert (a.A, a.B, a.C) == (b.A, b.B, b.C)
 
 
+@pytest.mark.parametrize("group", ["G1", "G2"])
+def test_key_conversion_scalar_multiplication_edge_scalars(ps_api, ctx, co, pr, group):
+    """The scalar multiplication inside ps_points_monomial_to_lagrange (csrc/lagrange.hpp, ec_mul_glv: k = k1 + k2 lambda with
+    lambda P = (beta x, y), both halves in signed radix-16 digits over one table) against the oracle's Point.Mul, scalar by
+    scalar, on the values a random twiddle never hits: 0, 1, the neighbours of lambda and of 2^128, r - 1, digit patterns of
+    all -8 / all 7 / all 0, and the identity as the point (ps_debug_points_scale: a test hook, not in the header)."""
+    import ctypes as C
+
+    lam = pr.BLS_Z * pr.BLS_Z - 1
+    assert (lam * lam + lam + 1) % pr.R == 0
+    R = pr.R
+    rng = pr.SplitMix64(SEED + 4242)
+    nib = lambda d: sum(d << (4 * i) for i in range(32))  # the same nibble 32 times
+    edge = [0, 1, 2, 7, 8, 9, 15, 16, lam - 1, lam, lam + 1, 2 * lam, lam * lam % R, R - 1, R - 2, R - lam, (1 << 128) - 1, 1 << 128,
+            (1 << 128) + 1, (1 << 255) % R, nib(0x8), nib(0x7), nib(0xF), nib(0x8) * (lam + 1) % R, (nib(0x7) + nib(0x7) * lam) % R,
+            (lam - 1) + (lam - 1) * lam, 8 * lam + 8, (R - 1) // 2]
+    ks = [k % R for k in edge] + [rng.fr() for _ in range(36)]
+    G = getattr(co, group)
+    gid = ps_api.G1 if group == "G1" else ps_api.G2
+    base = [G.mul(rng.fr()) for _ in range(4)]
+    pts = [base[i % 4] for i in range(len(ks))]
+    ident = G.to_b(None)
+    raw = G.pack(pts) + ident  # ... and the identity as the last point
+    ks.append(rng.fr())
+    dpts = ps_api.Points.upload(ctx, gid, raw)
+    dks = ps_api.Poly.upload(ctx, ks)
+    lib = ps_api.lib
+    lib.ps_debug_points_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ps_debug_points_scale.restype = C.c_int
+    h = C.c_void_p()
+    ps_api._check(lib.ps_debug_points_scale(ctx._h, dpts._h, dks._h, C.byref(h)))
+    got = ps_api.Points(ctx, h).download()
+    for i, k in enumerate(ks[:-1]):
+        want = G.to_b(G.mul(k, pts[i])) if k else ident
+        assert got[i * G.nb:(i + 1) * G.nb] == want, (group, i, hex(k))
+    assert got[-G.nb:] == ident  # k * O = O
+
+
 @pytest.mark.parametrize("n", [4, 37, 200])
 def test_groth16_trusted_setup_on_device(ps_api, ctx, co, pr, n):
     """NewGroth16TrustedSetup (groth16.go:64-101) on the device against the oracle: every CRS array
