@@ -64,6 +64,18 @@ def test_tail_kernels_fit_beside_an_accumulation_wave(code_object):
         assert int(notes[n]["vgpr_count"]) + int(notes[n]["agpr_count"]) <= 256, (n, notes[n])
 
 
+def test_key_conversion_kernels_of_g1_run_two_waves_per_simd(code_object):
+    """k_ec_ntt_stage / k_ec_scale (csrc/lagrange.hpp: a GLV scalar multiplication per thread, its point operations inlined)
+    are latency chains of dependent multiply-adds: the G1 instances must stay within 256 registers without spilling so that
+    two waves share a SIMD (2^20-constraint key: 11.2 -> 8.6 s per G1 array)."""
+    notes = kernel_notes(code_object)
+    ec = [n for n in notes if re.search(r"k_ec_ntt_stageINS_2FpE|k_ec_scaleINS_2FpE", n)]
+    assert len(ec) == 3, ec
+    for n in ec:
+        assert int(notes[n]["vgpr_count"]) + int(notes[n]["agpr_count"]) <= 256, (n, notes[n])
+        assert int(notes[n]["vgpr_spill_count"]) == 0, (n, notes[n])
+
+
 def test_accumulation_kernels_hold_the_mixed_addition_inline(code_object):
     asm = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", code_object], check=True, capture_output=True, text=True).stdout
     bodies = {}
