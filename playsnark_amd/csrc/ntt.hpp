@@ -179,7 +179,7 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
 #if defined(PS_NTT_X_NEARTW)  // (timing experiment only: every twiddle from the same two cache lines -- wrong results)
         w = tw[blk & 1u];
 #else
-        w = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
+        w = tw[((size_t)1 << M) + blk];  // the compact table (NttTables::cfwd / cinv)
 #endif
         return true;
     };
@@ -505,10 +505,24 @@ static int g_ntt_launch_no = 0;
 static int g_ntt_trace_meta[6] = {0, 0, 0, 0, 0, 0};  // grid, k, logD, inverse, p, threads of the traced launch
 #endif
 struct NttTables {
-    Fr* fwd = nullptr;
+    Fr* fwd = nullptr;   // w^i, i < 2^(log_tab-1)
     Fr* inv = nullptr;
+    // The same values in the order the passes read them: level M (2^M blocks per transform at a stage) at [2^M, 2^(M+1)), block
+    // order inside the level -- cfwd[2^M + blk] = w_{2^(M+1)}^bitrev_M(blk).  With the power table every block's twiddle sits
+    // in a cache line of its own at a bit-reversed place; here the 64 twiddles a wave needs at a low stage are 2.5 KB in a row.
+    Fr* cfwd = nullptr;
+    Fr* cinv = nullptr;
     int log_tab = 0;
 };
+// c[idx] for idx in [2, 2^log_tab): level M = floor(log2 idx), block idx - 2^M   (c[0], c[1] = 1: never read)
+__global__ void __launch_bounds__(256) k_twiddle_compact(Fr* __restrict__ c, const Fr* __restrict__ tw, int log_tab) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (1u << log_tab)) return;
+    if (idx < 2) { c[idx] = fr_one(); return; }
+    const int M = 31 - __clz(idx);
+    const u32 blk = idx - (1u << M);
+    c[idx] = tw[(size_t)(__brev(blk) >> (32 - M)) << (log_tab - 1 - M)];
+}
 
 static inline int ilog2_ceil(u64 v) {
     int l = 0;
@@ -522,13 +536,21 @@ static inline hipError_t ntt_tables_ensure(NttTables& t, int log_size, hipStream
     if (t.log_tab >= log_size) return hipSuccess;
     if (log_size > 32) return hipErrorInvalidValue;
     hipError_t e;
-    if (t.fwd) { (void)hipStreamSynchronize(st); (void)hipFree(t.fwd); (void)hipFree(t.inv); t.fwd = t.inv = nullptr; t.log_tab = 0; }
+    if (t.fwd) {
+        (void)hipStreamSynchronize(st);
+        for (Fr** p : {&t.fwd, &t.inv, &t.cfwd, &t.cinv}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+        t.log_tab = 0;
+    }
     size_t entries = (size_t)1 << (log_size - 1);
     if ((e = hipMalloc((void**)&t.fwd, entries * sizeof(Fr))) != hipSuccess) return e;
     if ((e = hipMalloc((void**)&t.inv, entries * sizeof(Fr))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&t.cfwd, 2 * entries * sizeof(Fr))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&t.cinv, 2 * entries * sizeof(Fr))) != hipSuccess) return e;
     unsigned blocks = (unsigned)((entries + 255) / 256);
     hipLaunchKernelGGL(k_twiddle_table, dim3(blocks), dim3(256), 0, st, t.fwd, log_size, 0);
     hipLaunchKernelGGL(k_twiddle_table, dim3(blocks), dim3(256), 0, st, t.inv, log_size, 1);
+    hipLaunchKernelGGL(k_twiddle_compact, dim3(2 * blocks), dim3(256), 0, st, t.cfwd, (const Fr*)t.fwd, log_size);
+    hipLaunchKernelGGL(k_twiddle_compact, dim3(2 * blocks), dim3(256), 0, st, t.cinv, (const Fr*)t.inv, log_size);
     t.log_tab = log_size;
     return hipGetLastError();
 }
@@ -662,7 +684,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         }
 #endif
         hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
-                           INV ? tb.inv : tb.fwd, tb.log_tab, fz, scale_log);
+                           INV ? tb.cinv : tb.cfwd, tb.log_tab, fz, scale_log);
 #if defined(PS_NTT_TUNE)
         if (trace_this) {
             (void)hipStreamSynchronize(st);
@@ -716,7 +738,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int logCols; unsigned grid, threads; size_t smem;
         shape(k, logCols, grid, smem, threads);
         const NttFuse fz = i == 0 ? ld_fuse : NttFuse();
-        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.fwd, tb.log_tab, fz, 0);
+        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cfwd, tb.log_tab, fz, 0);
         done += k;
     }
     const int km = ks[npass - 1];
@@ -728,7 +750,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int scale_log = 0;
         const int next_k = npass > 1 ? ks[npass - 2] : 0;
         if (npass == 1 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
-        hipLaunchKernelGGL(k_ntt_mid, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.fwd, (const Fr*)tb.inv, tb.log_tab, fl, fs,
+        hipLaunchKernelGGL(k_ntt_mid, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.cfwd, (const Fr*)tb.cinv, tb.log_tab, fl, fs,
                            aux, aux_mask, scale_log);
     }
     done = km;
@@ -741,7 +763,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int scale_log = 0;
         const int next_k = i > 0 ? ks[i - 1] : 0;
         if (i == 0 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
-        hipLaunchKernelGGL(k_ntt_pass<true>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.inv, tb.log_tab, fz, scale_log);
+        hipLaunchKernelGGL(k_ntt_pass<true>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cinv, tb.log_tab, fz, scale_log);
         done += k;
     }
     return hipGetLastError();

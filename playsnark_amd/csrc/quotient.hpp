@@ -33,8 +33,8 @@ struct QuotientCache {  // per-context NTT state
 };
 static inline void quotient_cache_free(QuotientCache* q) {
     if (!q) return;
-    if (q->tabs.fwd) (void)hipFree(q->tabs.fwd);
-    if (q->tabs.inv) (void)hipFree(q->tabs.inv);
+    for (Fr* t : {q->tabs.fwd, q->tabs.inv, q->tabs.cfwd, q->tabs.cinv})
+        if (t) (void)hipFree(t);
     delete q;
 }
 
