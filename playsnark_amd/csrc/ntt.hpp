@@ -49,6 +49,12 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
 // workgroups per CU, transforms of 2^20 in two passes) 11.3 / 2.9 ms; 1024 elements (40 KB, four 256-thread workgroups per
 // CU, three passes) 10.6-10.9 / 2.65-2.7 ms; 512 elements 10.9 / 2.7 ms.  The passes are bound by their instruction count,
 // not by HBM, so the extra pass costs less than the finer interleaving of load, butterfly and store phases gains.
+// Waves per SIMD the pass kernels are compiled for.  Until late in round 4: four (128 registers per lane, four 40 KB tiles per
+// CU), at the price of 10-14 spilled registers in k_ntt_mid and the inverse pass.  Three (the compiler then takes 137-139
+// registers, nothing spilled): the quotient at 2^20 gates 8.96 -> 8.70 ms, 3-7 % at every size from 2^10 up (A/B on one box).
+#ifndef PS_NTT_WAVES
+#define PS_NTT_WAVES 3
+#endif
 constexpr int NTT_MAX_K = 9;        // butterfly stages per pass (a tile then keeps >= 2 contiguous columns = 80 B runs)
 constexpr int NTT_TILE_LOG = 10;    // 1024 Fr = 40 KB of LDS per workgroup
 
@@ -86,7 +92,7 @@ struct NttFuse {
     int st_member_log = 0;
 };
 
-// __launch_bounds__(512, 4): hipcc's second argument is waves per SIMD, not blocks per CU.  Four 256-thread workgroups
+// __launch_bounds__(512, PS_NTT_WAVES): hipcc's second argument is waves per SIMD, not blocks per CU.  Four 256-thread workgroups
 // per CU (two of 512 with the 80 KB tile) need 4 waves per SIMD, i.e. at most 128 VGPRs; with "2" the inverse pass took 139 and ran one workgroup per CU
 // (measured: no difference in the quotient's time either way -- the passes are bound by their instruction count).
 #if defined(PS_NTT_TUNE)
@@ -252,7 +258,7 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
 }
 
 template <bool INV>
-__global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
+__global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
                                                   const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
     Fr* tile = reinterpret_cast<Fr*>(ntt_smem);
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__(512, 4) k_ntt_pass(Fr* __restrict__ data, int 
 // DESIGN.md section 6; the quotient of the reference's key form is ~150 such passes at 2^20).  first / last: the load
 // fusion of the forward's first pass and the store fusion (and scaling) of the inverse's last pass apply here too when the
 // transform fits one tile.
-__global__ void __launch_bounds__(512, 4) k_ntt_mid(Fr* __restrict__ data, int p, int k, int logCols, const Fr* __restrict__ tw_fwd,
+__global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_mid(Fr* __restrict__ data, int p, int k, int logCols, const Fr* __restrict__ tw_fwd,
                                                  const Fr* __restrict__ tw_inv, int log_tab, NttFuse fl, NttFuse fs, const Fr* __restrict__ aux,
                                                  u64 aux_mask, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
