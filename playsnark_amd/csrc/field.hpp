@@ -884,10 +884,21 @@ PS_INL Fr fr_propagate(const Fr& a) {
     r.l[FR_L - 1] = a.l[FR_L - 1] + c;
     return r;
 }
-PS_INL Fr fr_mul(const Fr& a, const Fr& b) {
+PS_INL Fr fr_mul(const Fr& a_in, const Fr& b_in) {
     Fr r;
     i32 m[FR_L];
     i64 acc = 0;
+    // Operand limbs that are fresh 32-bit sums (the lazy additions of a butterfly) must reach the products AS 32-bit values:
+    // otherwise the compiler widens the sum (sext(x + y) = sext(x) + sext(y), no signed overflow) and multiplies 64 x 64 bits --
+    // two v_mul_lo_u32, a v_mad_u64_u32 and a v_add3_u32 where one v_mad_i64_i32 does it.  The first operand only: the second
+    // is a twiddle or a constant, often in SGPRs.  (At four waves per SIMD the barrier cost more in spilled registers than it
+    // saved; at three -- ntt.hpp, PS_NTT_WAVES -- the quotient at 2^20 gates goes from 8.58 to 8.37 ms.)
+    Fr a = a_in;
+    const Fr& b = b_in;  // (a barrier on this one too: measured, nothing)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FR_MUL_NO_BARRIER)
+#pragma unroll
+    for (int i = 0; i < FR_L; i++) asm("" : "+v"(a.l[i]));
+#endif
     // The top limb of r is 7: left as a literal the compiler multiplies by it with a v_mul_lo_u32 and adds the product with a
     // 64-bit add (two quarter-rate instructions) where a multiply-add does both -- so it is handed over as an opaque scalar.
     i32 mod_top = fr_mod28(FR_L - 1);
