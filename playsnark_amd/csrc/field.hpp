@@ -916,7 +916,11 @@ PS_INL Fr fr_mul(const Fr& a_in, const Fr& b_in) {
         // not a (quarter-rate) v_mul_lo_u32
         static_assert(FR_INV28 == FP_MASK, "m = -acc mod 2^28 needs r = 1 mod 2^28");
         m[k] = (i32)((0u - (u32)acc) & FP_MASK);
-        acc += (i64)m[k] * (i64)fr_mod28(0);
+        // acc + m[k] * r_0 with r_0 = 1: the low 28 bits cancel, so (acc + m[k]) >> 28 = ceil(acc / 2^28) = (acc + 2^28 - 1) >> 28
+        // -- a CONSTANT addend, which the compiler folds into the column's first multiply-add, where m[k] (a register) costs a
+        // 64-bit add of its own: ten quarter-rate instructions less per product.
+        static_assert(fr_mod28(0) == 1, "the ceiling trick needs r = 1 mod 2^28");
+        acc += (i64)FP_MASK;
         acc >>= 28;
     }
 #pragma unroll
