@@ -81,7 +81,7 @@ __device__ inline Fr fr_sub_mul_small_div_2p28(const Fr& up, const Fr& coef, u32
     const i32 nc = -(i32)c;
     i64 acc = (i64)up.l[0] + (i64)nc * (i64)coef.l[0];
     const i32 m = (i32)((0u - (u32)acc) & FP_MASK);
-    acc = (acc + (i64)m) >> 28;
+    acc = (acc + (i64)FP_MASK) >> 28;  // = (acc + m r_0) >> 28 with r_0 = 1: the low bits cancel, a ceiling (field.hpp, fr_mul)
 #pragma unroll
     for (int i = 1; i < FR_L; i++) {
         acc += (i64)up.l[i] + (i64)nc * (i64)coef.l[i] + (i64)m * (i64)fr_mod28(i);
