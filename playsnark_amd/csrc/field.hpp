@@ -885,53 +885,14 @@ PS_INL Fr fr_propagate(const Fr& a) {
     return r;
 }
 #if defined(__HIP_DEVICE_COMPILE__)
-// One multiply-add of the chain below, in the order WRITTEN: acc + x * y.  (Left to the compiler, the products of a column are
-// summed as independent chains -- good for a lone wave's latency, but every merge is a 64-bit add that costs the issue time of
-// a multiply-add: 27 of them per product.)
-__device__ inline __attribute__((always_inline)) i64 fr_mad_vv(i32 x, i32 y, i64 acc) {
-    i64 d;
-    u64 cy;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(x), "v"(y), "v"(acc));
-    return d;
-}
-__device__ inline __attribute__((always_inline)) i64 fr_mad_vs(i32 x, i32 y_sgpr, i64 acc) {
-    i64 d;
-    u64 cy;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(x), "s"(y_sgpr), "v"(acc));
-    return d;
-}
 // The Montgomery product as ONE chain of multiply-adds per column, carried in the NEGATED domain: N_k = -(column sum).  Then
 // the Montgomery digit is N_k mod 2^28 itself (r = 1 mod 2^28), the carry into the next column is N_k >> 28 (the floor of the
 // negated sum is the negated CEILING the positive sum needs, see fr_mul), the modulus enters as the constants -r_j, and the
 // result's limbs come out as -(N_k mod 2^28): non-positive limbs, the same value, inside the lazy-limb contract like any
-// difference.  194 multiply-adds, 19 shifts, 19 masks, 20 negations; no 64-bit add.
-__device__ inline __attribute__((always_inline)) Fr fr_mul_chain(const Fr& a, const Fr& b) {
-    Fr r;
-    i32 na[FR_L], m[FR_L];
-#pragma unroll
-    for (int i = 0; i < FR_L; i++) na[i] = -a.l[i];
-    i64 acc = 0;
-#pragma unroll
-    for (int k = 0; k < FR_L; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) acc = fr_mad_vv(na[i], b.l[k - i], acc);
-#pragma unroll
-        for (int i = 0; i < k; i++) acc = fr_mad_vs(m[i], -fr_mod28(k - i), acc);
-        m[k] = (i32)((u32)acc & FP_MASK);
-        acc >>= 28;  // (N_k - m_k) / 2^28 = floor(N_k / 2^28): the term -m_k r_0 cancels the low bits
-    }
-#pragma unroll
-    for (int k = FR_L; k < 2 * FR_L - 1; k++) {
-#pragma unroll
-        for (int i = k - FR_L + 1; i < FR_L; i++) acc = fr_mad_vv(na[i], b.l[k - i], acc);
-#pragma unroll
-        for (int i = k - FR_L + 1; i < FR_L; i++) acc = fr_mad_vs(m[i], -fr_mod28(k - i), acc);
-        r.l[k - FR_L] = -(i32)((u32)acc & FP_MASK);
-        acc >>= 28;
-    }
-    r.l[FR_L - 1] = -(i32)acc;
-    return r;
-}
+// difference.  194 multiply-adds, 19 shifts, 19 masks, 20 negations; no 64-bit add.  (Left to the compiler, the products of a
+// column are summed as independent chains -- good for a lone wave's latency, but every merge is a 64-bit add that costs the
+// issue time of a multiply-add: 27 of them per product.)  The code is generated: tools/gen_fr_chain.py.
+#include "fr_chain.inc"
 #endif
 PS_INL Fr fr_mul(const Fr& a_in, const Fr& b_in) {
     Fr r;
