@@ -895,6 +895,12 @@ PS_INL Fr fr_propagate(const Fr& a) {
 #include "fr_chain.inc"
 #endif
 PS_INL Fr fr_mul(const Fr& a_in, const Fr& b_in) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FR_MUL_NO_CHAIN)
+    // On the device: the single-chain form above.  With a statement per multiply-add (194 compiler-inserted wait states per
+    // product) it won only where the chip was full of waves (2^20 gates: -2.5 %) and lost 10 % at 2^10 .. 2^16 gates; with a
+    // statement per column it wins 2-6 % at every size (A/B against the code below, 2^10 .. 2^20 gates).
+    return fr_mul_chain(a_in, b_in);
+#endif
     Fr r;
     i32 m[FR_L];
     i64 acc = 0;
@@ -944,16 +950,6 @@ PS_INL Fr fr_mul(const Fr& a_in, const Fr& b_in) {
     }
     r.l[FR_L - 1] = (i32)acc;
     return r;
-}
-// The product for kernels that are compiled twice (ntt.hpp): CHAIN = the single-chain form above, which wins where the chip is
-// full of waves (transforms of 2^21 elements and more: -2.5 %) and loses where a launch is a few waves deep in latency
-// (2^10 .. 2^16 gates: +10 %), because a lone wave cannot issue its dependent multiply-adds back to back.
-template <bool CHAIN>
-PS_INL Fr fr_mul_sel(const Fr& a, const Fr& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (CHAIN) return fr_mul_chain(a, b);
-#endif
-    return fr_mul(a, b);
 }
 // canonical representative in [0, r) for V in (-2r, 3r)
 PS_INL Fr fr_canon(const Fr& a) {

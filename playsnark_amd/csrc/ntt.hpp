@@ -55,10 +55,6 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
 #ifndef PS_NTT_WAVES
 #define PS_NTT_WAVES 3
 #endif
-// Launches over this many elements use the kernels compiled with the single-chain field product (fr_mul_chain): the chip is
-// full of waves then; below, a launch is latency and the compiler's interleaved chains are faster (A/B: 2^10 .. 2^16 gates
-// 10 % slower with the chain, 2^18 equal, 2^20 2.5 % faster).
-constexpr unsigned long long NTT_CHAIN_MIN_TOTAL = 1ull << 21;
 constexpr int NTT_MAX_K = 9;        // butterfly stages per pass (a tile then keeps >= 2 contiguous columns = 80 B runs)
 constexpr int NTT_TILE_LOG = 10;    // 1024 Fr = 40 KB of LDS per workgroup
 
@@ -169,7 +165,7 @@ PS_INL void ntt_store_fused(Fr* __restrict__ data, u64 addr, const Fr& v, const 
 #else
 #define PS_NTT_SW(i) ((i) ^ (((i) >> 5) & 31u))
 #endif
-template <bool INV, bool CHAIN>
+template <bool INV>
 __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, const NttTile& g, const Fr* __restrict__ tw, int log_tab) {
     const int p = g.p, logD = g.logD, k = g.k, logCols = g.logCols;
     const u32 COLS = 1u << logCols, rows = 1u << k;
@@ -209,13 +205,13 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                 Fr a = tile[PS_NTT_SW(t0 * COLS + col)], b = tile[PS_NTT_SW(t1 * COLS + col)], w;
                 const bool has_w = twiddle(gidx(t0, col), logh, w);
                 if (!INV) {
-                    Fr wb = has_w ? fr_mul_sel<CHAIN>(b, w) : b;
+                    Fr wb = has_w ? fr_mul(b, w) : b;
                     tile[PS_NTT_SW(t0 * COLS + col)] = fr_norm(fr_add(a, wb));
                     tile[PS_NTT_SW(t1 * COLS + col)] = fr_norm(fr_sub(a, wb));
                 } else {
                     tile[PS_NTT_SW(t0 * COLS + col)] = fr_norm(fr_add(a, b));
                     Fr d = fr_norm(fr_sub(a, b));
-                    tile[PS_NTT_SW(t1 * COLS + col)] = has_w ? fr_mul_sel<CHAIN>(d, w) : d;
+                    tile[PS_NTT_SW(t1 * COLS + col)] = has_w ? fr_mul(d, w) : d;
                 }
             }
             done_st += 1;
@@ -231,28 +227,28 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
                 Fr w;
                 if (!INV) {
                     // stage m_hi: (a, c), (b, d) share one block; stage m_lo: (a', b') and (c', d')
-                    if (twiddle(i00, logD + m_hi, w)) { c = fr_mul_sel<CHAIN>(c, w); d = fr_mul_sel<CHAIN>(d, w); }
+                    if (twiddle(i00, logD + m_hi, w)) { c = fr_mul(c, w); d = fr_mul(d, w); }
                     Fr a1 = fr_add(a, c), c1 = fr_sub(a, c), b1 = fr_add(b, d), d1 = fr_sub(b, d);  // class 2, fresh sums
                     twiddle(i00, logD + m_lo, w);  // m_lo < k-1: never the outermost stage
-                    Fr wb = fr_mul_sel<CHAIN>(b1, w);
+                    Fr wb = fr_mul(b1, w);
                     tile[PS_NTT_SW(t00 * COLS + col)] = PS_NTT_FNORM(fr_add(a1, wb));
                     tile[PS_NTT_SW(t01 * COLS + col)] = PS_NTT_FNORM(fr_sub(a1, wb));
                     twiddle(i10, logD + m_lo, w);
-                    Fr wd = fr_mul_sel<CHAIN>(d1, w);
+                    Fr wd = fr_mul(d1, w);
                     tile[PS_NTT_SW(t10 * COLS + col)] = PS_NTT_FNORM(fr_add(c1, wd));
                     tile[PS_NTT_SW(t11 * COLS + col)] = PS_NTT_FNORM(fr_sub(c1, wd));
                 } else {
                     // stage m_lo: (a, b) and (c, d) in neighbouring blocks; stage m_hi: (a', c'), (b', d')
                     twiddle(i00, logD + m_lo, w);  // m_lo < the outermost stage: always a real twiddle
-                    Fr a1 = fr_add(a, b), b1 = fr_mul_sel<CHAIN>(fr_norm(fr_sub(a, b)), w);
+                    Fr a1 = fr_add(a, b), b1 = fr_mul(fr_norm(fr_sub(a, b)), w);
                     twiddle(i10, logD + m_lo, w);
-                    Fr c1 = fr_add(c, d), d1 = fr_mul_sel<CHAIN>(fr_norm(fr_sub(c, d)), w);
+                    Fr c1 = fr_add(c, d), d1 = fr_mul(fr_norm(fr_sub(c, d)), w);
                     const bool has_w = twiddle(i00, logD + m_hi, w);
                     tile[PS_NTT_SW(t00 * COLS + col)] = fr_norm(fr_add(a1, c1));
                     tile[PS_NTT_SW(t01 * COLS + col)] = fr_norm(fr_add(b1, d1));
                     Fr e = fr_norm(fr_sub(a1, c1)), f = fr_norm(fr_sub(b1, d1));
-                    tile[PS_NTT_SW(t10 * COLS + col)] = has_w ? fr_mul_sel<CHAIN>(e, w) : e;
-                    tile[PS_NTT_SW(t11 * COLS + col)] = has_w ? fr_mul_sel<CHAIN>(f, w) : f;
+                    tile[PS_NTT_SW(t10 * COLS + col)] = has_w ? fr_mul(e, w) : e;
+                    tile[PS_NTT_SW(t11 * COLS + col)] = has_w ? fr_mul(f, w) : f;
                 }
             }
             done_st += 2;
@@ -261,7 +257,7 @@ __device__ inline __attribute__((always_inline)) void ntt_tile_stages(Fr* tile, 
     }
 }
 
-template <bool INV, bool CHAIN>
+template <bool INV>
 __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_pass(Fr* __restrict__ data, int p, int logD, int k, int logCols,
                                                   const Fr* __restrict__ tw, int log_tab, NttFuse fz, int scale_log) {
     extern __shared__ __align__(16) unsigned char ntt_smem[];
@@ -277,7 +273,7 @@ __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_pass(Fr* __restrict__
     }
     __syncthreads();
     PS_NTT_STAMP(1);
-    ntt_tile_stages<INV, CHAIN>(tile, g, tw, log_tab);
+    ntt_tile_stages<INV>(tile, g, tw, log_tab);
     // The inverse doubles along the all-sums path (a product pulls a value back under 2r, a sum does not);
     // 2^16 r still fits the lazy limbs with room to spare (top limb < 2^20), so ntt_run asks for the
     // scaling 2^-scale_log only in the last pass of a transform, or earlier for very long ones.
@@ -293,7 +289,7 @@ __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_pass(Fr* __restrict__
         ntt_tile_map(g, e, addr, slot);
         Fr v = tile[PS_NTT_SW(slot)];
 #if !defined(PS_NTT_X_NOSCALE)  // (timing experiment only: the inverse's scaling product left out -- wrong results)
-        if (INV && scale_log) v = fr_mul_sel<CHAIN>(v, sc);
+        if (INV && scale_log) v = fr_mul(v, sc);
 #endif
         ntt_store_fused(data, addr, v, fz);
     }
@@ -307,7 +303,6 @@ __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_pass(Fr* __restrict__
 // DESIGN.md section 6; the quotient of the reference's key form is ~150 such passes at 2^20).  first / last: the load
 // fusion of the forward's first pass and the store fusion (and scaling) of the inverse's last pass apply here too when the
 // transform fits one tile.
-template <bool CHAIN>
 __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_mid(Fr* __restrict__ data, int p, int k, int logCols, const Fr* __restrict__ tw_fwd,
                                                  const Fr* __restrict__ tw_inv, int log_tab, NttFuse fl, NttFuse fs, const Fr* __restrict__ aux,
                                                  u64 aux_mask, int scale_log) {
@@ -322,15 +317,15 @@ __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_mid(Fr* __restrict__ 
         tile[PS_NTT_SW(slot)] = ntt_load_fused(data, addr, fl);
     }
     __syncthreads();
-    ntt_tile_stages<false, CHAIN>(tile, g, tw_fwd, log_tab);
+    ntt_tile_stages<false>(tile, g, tw_fwd, log_tab);
     for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
         u64 addr;
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
-        tile[PS_NTT_SW(slot)] = fr_mul_sel<CHAIN>(tile[PS_NTT_SW(slot)], aux[addr & aux_mask]);
+        tile[PS_NTT_SW(slot)] = fr_mul(tile[PS_NTT_SW(slot)], aux[addr & aux_mask]);
     }
     __syncthreads();
-    ntt_tile_stages<true, CHAIN>(tile, g, tw_inv, log_tab);
+    ntt_tile_stages<true>(tile, g, tw_inv, log_tab);
     Fr sc;
     if (scale_log) {
 #pragma unroll
@@ -341,7 +336,7 @@ __global__ void __launch_bounds__(512, PS_NTT_WAVES) k_ntt_mid(Fr* __restrict__ 
         u32 slot;
         ntt_tile_map(g, e, addr, slot);
         Fr v = tile[PS_NTT_SW(slot)];
-        if (scale_log) v = fr_mul_sel<CHAIN>(v, sc);
+        if (scale_log) v = fr_mul(v, sc);
         ntt_store_fused(data, addr, v, fs);
     }
 }
@@ -571,9 +566,9 @@ static inline hipError_t ntt_tables_ensure(NttTables& t, int log_size, hipStream
 static inline hipError_t ntt_tune_raise_lds() {
     static bool raised = false;
     if (raised) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_mid<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_pass<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ntt_mid), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = e == hipSuccess;
     return e;
 }
@@ -694,12 +689,8 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
             g_ntt_trace_meta[4] = p; g_ntt_trace_meta[5] = (int)threads;
         }
 #endif
-        if (total >= NTT_CHAIN_MIN_TOTAL)
-            hipLaunchKernelGGL((k_ntt_pass<INV, true>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
-                               INV ? tb.cinv : tb.cfwd, tb.log_tab, fz, scale_log);
-        else
-            hipLaunchKernelGGL((k_ntt_pass<INV, false>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
-                               INV ? tb.cinv : tb.cfwd, tb.log_tab, fz, scale_log);
+        hipLaunchKernelGGL(k_ntt_pass<INV>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols,
+                           INV ? tb.cinv : tb.cfwd, tb.log_tab, fz, scale_log);
 #if defined(PS_NTT_TUNE)
         if (trace_this) {
             (void)hipStreamSynchronize(st);
@@ -728,7 +719,6 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
     if (ntt_tune_raise_lds() != hipSuccess) return hipErrorInvalidValue;
 #endif
     const int npass = p <= tile_log ? 1 : (p + max_k - 1) / max_k;
-    const bool chain = total >= NTT_CHAIN_MIN_TOTAL;  // which form of the field product the passes are compiled with (field.hpp, fr_mul_sel)
     int ks[8];  // forward order (from the top); the inverse walks the same groups back
     {
         int left = p;
@@ -754,8 +744,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int logCols; unsigned grid, threads; size_t smem;
         shape(k, logCols, grid, smem, threads);
         const NttFuse fz = i == 0 ? ld_fuse : NttFuse();
-        if (chain) hipLaunchKernelGGL((k_ntt_pass<false, true>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cfwd, tb.log_tab, fz, 0);
-        else hipLaunchKernelGGL((k_ntt_pass<false, false>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cfwd, tb.log_tab, fz, 0);
+        hipLaunchKernelGGL(k_ntt_pass<false>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cfwd, tb.log_tab, fz, 0);
         done += k;
     }
     const int km = ks[npass - 1];
@@ -767,12 +756,8 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int scale_log = 0;
         const int next_k = npass > 1 ? ks[npass - 2] : 0;
         if (npass == 1 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
-        if (chain)
-            hipLaunchKernelGGL(k_ntt_mid<true>, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.cfwd, (const Fr*)tb.cinv, tb.log_tab,
-                               fl, fs, aux, aux_mask, scale_log);
-        else
-            hipLaunchKernelGGL(k_ntt_mid<false>, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.cfwd, (const Fr*)tb.cinv, tb.log_tab,
-                               fl, fs, aux, aux_mask, scale_log);
+        hipLaunchKernelGGL(k_ntt_mid, dim3(grid), dim3(threads), smem, st, data, p, km, logCols, (const Fr*)tb.cfwd, (const Fr*)tb.cinv, tb.log_tab, fl, fs,
+                           aux, aux_mask, scale_log);
     }
     done = km;
     for (int i = npass - 2; i >= 0; i--) {  // inverse passes, upwards
@@ -784,8 +769,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
         int scale_log = 0;
         const int next_k = i > 0 ? ks[i - 1] : 0;
         if (i == 0 || unscaled + next_k > 16) { scale_log = unscaled; unscaled = 0; }
-        if (chain) hipLaunchKernelGGL((k_ntt_pass<true, true>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cinv, tb.log_tab, fz, scale_log);
-        else hipLaunchKernelGGL((k_ntt_pass<true, false>), dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cinv, tb.log_tab, fz, scale_log);
+        hipLaunchKernelGGL(k_ntt_pass<true>, dim3(grid), dim3(threads), smem, st, data, p, logD, k, logCols, tb.cinv, tb.log_tab, fz, scale_log);
         done += k;
     }
     return hipGetLastError();
