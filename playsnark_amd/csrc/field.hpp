@@ -371,9 +371,18 @@ PS_INL Fp fp_propagate(const Fp& a) {
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same products as one chain of multiply-adds per column (generated: tools/gen_fp_chain.py; the why is at fr_mul_chain):
+// the compiler's code sums each column as independent chains and pays a 64-bit add per merge -- 260 quarter-rate adds per
+// mixed addition of the bucket accumulation, 5.7 % of its issue time.
+#include "fp_chain.inc"
+#endif
 // Montgomery product, product scanning: column k sums a[i]*b[k-i] and m[i]*p[k-i] in one signed
 // 64-bit accumulator (v_mad_i64_i32 chains), m[k] = -acc/p mod 2^28 clears the low 28 bits.
 PS_INL Fp f_mul(const Fp& a, const Fp& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP_MUL_NO_CHAIN)
+    return f_mul_chain(a, b);
+#endif
     Fp r;
     i32 m[FP_L];
     i64 acc = 0;
@@ -399,11 +408,19 @@ PS_INL Fp f_mul(const Fp& a, const Fp& b) {
     r.l[FP_L - 1] = (i32)acc;
     return r;
 }
-PS_INL Fp f_sqr(const Fp& a) { return f_mul(a, a); }  // the compiler folds the symmetric products
+PS_INL Fp f_sqr(const Fp& a) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP_MUL_NO_CHAIN)
+    return f_sqr_chain(a);
+#endif
+    return f_mul(a, a);  // the compiler folds the symmetric products
+}
 
 // a*b - c*d with ONE Montgomery reduction (588 mads instead of 784): both products accumulate in
 // the same columns.  Needs class(a)*class(b) + class(c)*class(d) <= 8.
 PS_INL Fp f_mul2sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP_MUL_NO_CHAIN)
+    return f_mul2sub_chain(a, b, c, d);
+#endif
     Fp r;
     i32 m[FP_L];
     i64 acc = 0;
@@ -438,6 +455,9 @@ PS_INL Fp f_mul2sub(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
 
 // a*b + c*d with one reduction (the complex product of the lane-split Fp2, below)
 PS_INL Fp f_mul2add(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP_MUL_NO_CHAIN)
+    return f_mul2add_chain(a, b, c, d);
+#endif
     Fp r;
     i32 m[FP_L];
     i64 acc = 0;
@@ -474,6 +494,9 @@ PS_INL Fp f_mul2add(const Fp& a, const Fp& b, const Fp& c, const Fp& d) {
 // operands' limb classes must satisfy class(a1)class(b1) + .. + class(s2)class(t2) <= 8.
 PS_INL Fp f_mul2add2sub(const Fp& a1, const Fp& b1, const Fp& a2, const Fp& b2, const Fp& s1, const Fp& t1, const Fp& s2,
                         const Fp& t2) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PS_FP_MUL_NO_CHAIN)
+    return f_mul2add2sub_chain(a1, b1, a2, b2, s1, t1, s2, t2);
+#endif
     Fp r;
     i32 m[FP_L];
     i64 acc = 0;
