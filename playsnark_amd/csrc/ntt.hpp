@@ -52,6 +52,8 @@ __global__ void __launch_bounds__(256) k_twiddle_table(Fr* __restrict__ tw, int 
 // Waves per SIMD the pass kernels are compiled for.  Until late in round 4: four (128 registers per lane, four 40 KB tiles per
 // CU), at the price of 10-14 spilled registers in k_ntt_mid and the inverse pass.  Three (the compiler then takes 137-139
 // registers, nothing spilled): the quotient at 2^20 gates 8.96 -> 8.70 ms, 3-7 % at every size from 2^10 up (A/B on one box).
+// With the field product as a single chain (field.hpp, fr_mul_chain) the kernels need 102-121 registers, so FOUR waves per SIMD
+// are resident again -- without spills; the bound below only keeps the compiler from trading registers for them.
 #ifndef PS_NTT_WAVES
 #define PS_NTT_WAVES 3
 #endif
