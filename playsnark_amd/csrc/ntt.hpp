@@ -581,7 +581,6 @@ template <bool INV>
 static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p, const NttFuse& fuse = NttFuse()) {
     if (p == 0) return (fuse.ld || fuse.st) ? hipErrorInvalidValue : hipSuccess;
     if (p > tb.log_tab) return hipErrorInvalidValue;
-    const int log_total = ilog2_ceil(total);
     // a transform that fits one tile runs all its stages in one pass (contiguous in HBM: no stride to respect);
     // longer ones are cut into passes of at most NTT_MAX_K stages (with the 80 KB tile of round 1, measured at 2^20:
     // 8 stages 12.25 ms, 9: 11.9, 10: 11.9; see the note at NTT_TILE_LOG for the tile size)
@@ -620,7 +619,7 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
         int k = ks[ps_i];
         int logD = INV ? done : (p - done - k);
         int logCols = tile_log - k;
-        if (logCols > log_total - k) logCols = log_total - k;
+        { const int free_cols = __builtin_ctzll(total >> k); if (logCols > free_cols) logCols = free_cols; }  // (total: any multiple of 2^p -- a batch of three)
         if (logCols < 0) logCols = 0;
         u64 cols_total = total >> k;
         unsigned grid = (unsigned)(cols_total >> logCols);
@@ -713,7 +712,6 @@ static inline hipError_t ntt_run(const NttTables& tb, hipStream_t st, Fr* data, 
 static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data, u64 total, int p, const NttFuse& ld_fuse, const NttFuse& st_fuse,
                                   const Fr* aux, u64 aux_mask = ~0ull) {
     if (p == 0 || p > tb.log_tab || st_fuse.st == NTT_ST_MUL || ld_fuse.st != NTT_ST_PLAIN || st_fuse.ld != NTT_LD_PLAIN) return hipErrorInvalidValue;
-    const int log_total = ilog2_ceil(total);
     int max_k = NTT_MAX_K, tile_log = NTT_TILE_LOG;
 #if defined(PS_NTT_TUNE)  // measurement builds: pass shapes from the environment, as in ntt_run
     if (const char* e = getenv("PS_NTT_MAXK")) max_k = atoi(e);
@@ -734,7 +732,7 @@ static inline hipError_t ntt_conv(const NttTables& tb, hipStream_t st, Fr* data,
     }
     auto shape = [&](int k, int& logCols, unsigned& grid, size_t& smem, unsigned& threads) {
         logCols = tile_log - k;
-        if (logCols > log_total - k) logCols = log_total - k;
+        { const int free_cols = __builtin_ctzll(total >> k); if (logCols > free_cols) logCols = free_cols; }  // (total: any multiple of 2^p -- a batch of three)
         if (logCols < 0) logCols = 0;
         grid = (unsigned)((total >> k) >> logCols);
         smem = ((size_t)sizeof(Fr) << k) << logCols;

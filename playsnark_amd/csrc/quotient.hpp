@@ -250,14 +250,15 @@ __global__ void __launch_bounds__(256) k_lagrange_weights(Fr* __restrict__ out, 
     Fr w = fr_mul(fr_mul(y[j], invfact[j]), invfact[n - 1 - j]);
     out[j] = ((n - 1 - j) & 1) ? fr_neg(w) : w;
 }
-// the same for A, B, C at once: out = [w^A | w^B | w^C | 0], each part L = 2^logL long (a batch of four transforms)
+// the same for A, B, C at once: out = [w^A | w^B | w^C], each part L = 2^logL long (a batch of THREE transforms: the passes take any
+// multiple of a tile -- until round 4's end the batch was padded to four with a transform of zeros, a third more work)
 struct FrPtr3 { const Fr* p[3]; };
 __global__ void __launch_bounds__(256) k_lagrange_weights3(Fr* __restrict__ out, FrPtr3 ys, const Fr* __restrict__ invfact, u64 n, int logL) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (4ull << logL)) return;
+    if (idx >= (3ull << logL)) return;
     const u64 j = idx & ((1ull << logL) - 1);
     const u32 k = (u32)(idx >> logL);
-    if (k == 3 || j >= n) { out[idx] = fr_zero(); return; }
+    if (j >= n) { out[idx] = fr_zero(); return; }
     const Fr* y = k == 0 ? ys.p[0] : k == 1 ? ys.p[1] : ys.p[2];
     Fr w = fr_mul(fr_mul(y[j], invfact[j]), invfact[n - 1 - j]);
     out[idx] = ((n - 1 - j) & 1) ? fr_neg(w) : w;
@@ -354,7 +355,7 @@ struct QapTables {
     Fr *t1 = nullptr, *data = nullptr, *scratch = nullptr, *pa = nullptr, *pb = nullptr;
     Fr* newton_scale = nullptr;  // 64: 2^(-28 (63 - L)), the scale lane L's coefficient enters k_newton_base with
     Fr* s4 = nullptr;            // 8np: the two interpolations of Groth16's route as ONE batch of transforms (any n, round 4) ...
-    bool batch_h = false;        // ... and, for short transforms only, the three convolutions of the h-values path as a batch of four
+    bool batch_h = false;        // ... and the three convolutions of the h-values path as a batch of three (every size since round 4's end)
     std::vector<void*> owned;
     void free_all() {
         for (void* p : owned) (void)hipFree(p);
@@ -363,8 +364,11 @@ struct QapTables {
     }
 };
 
+#ifndef PS_QT_BATCH_MAX_LOG
+#define PS_QT_BATCH_MAX_LOG 40
+#endif
 #ifndef QT_BATCH_MAX_L
-#define QT_BATCH_MAX_L (1ull << 16)  // transforms up to this length leave most of the chip idle: the h-values path batches its three convolutions
+#define QT_BATCH_MAX_L (1ull << PS_QT_BATCH_MAX_LOG)  // transforms up to this length leave most of the chip idle: the h-values path batches its three convolutions
 #endif
 #define QT_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return _e; } while (0)
 
@@ -452,11 +456,13 @@ static inline hipError_t quotient_h_values(const NttTables& tabs, hipStream_t st
     if (qt.s4 && qt.batch_h) {
         // Short transforms are latency: a 2^11-point transform is two workgroups walking eleven butterfly stages, ~40 us for
         // the forward and inverse pair whatever the chip could do beside it (kernel trace of Groth16Prove on 2^10 constraints:
-        // 0.23 of the quotient's 0.37 ms).  The three convolutions share the kernel 1/d, so they run as one batch of four
-        // transforms (the fourth is zeros: batches are powers of two) -- one pair of launches instead of three.
+        // 0.23 of the quotient's 0.37 ms).  The three convolutions share the kernel 1/d, so they run as one batch of THREE
+        // transforms -- one set of launches instead of three.  (Until the end of round 4 the batch was padded to four with a
+        // transform of zeros and used only below 2^16 gates, where the padding cost less than the launches: as a batch of
+        // three it wins at every size -- 2^16 gates 0.49 -> 0.33 ms, 2^18 0.77 -> 0.63, 2^20 2.16 -> 2.00.)
         const int logL = qt.lognp + 1;
-        hipLaunchKernelGGL(k_lagrange_weights3, dim3(nblk(4 * L)), dim3(256), 0, st, qt.s4, FrPtr3{{yA, yB, yC}}, qt.invfact, n, logL);
-        QT_TRY(ntt_conv(tabs, st, qt.s4, 4 * L, logL, NttFuse(), NttFuse(), qt.rhat, L - 1));
+        hipLaunchKernelGGL(k_lagrange_weights3, dim3(nblk(3 * L)), dim3(256), 0, st, qt.s4, FrPtr3{{yA, yB, yC}}, qt.invfact, n, logL);
+        QT_TRY(ntt_conv(tabs, st, qt.s4, 3 * L, logL, NttFuse(), NttFuse(), qt.rhat, L - 1));
         for (int k = 0; k < 3; k++) S[k] = qt.s4 + (u64)k * L;
     } else
     for (int k = 0; k < 3; k++) {
