@@ -90,6 +90,10 @@ struct ps_ctx {
     // the context keeps, so a call does not pay a hipMalloc and a hipFree (which synchronises the device) of 32 bytes per
     // scalar on top of its copy over PCIe
     struct ps_scalars* up_scalars = nullptr;
+    // the provers' own scalar vectors (Groth16: SA, SB, SC; PHGR13: h), kept between proofs like up_scalars: a hipMalloc and a
+    // hipFree of 32 MB each per proof were ~1 ms of host time at 2^20 constraints, the free synchronising the device
+    struct ps_scalars* pv_scalars[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pv_cap[4] = {0, 0, 0, 0};
     size_t up_cap = 0;
     DevBuf fb_table[2];              // fixed-base tables (G1, G2)
     bool fb_ready[2] = {false, false};
@@ -276,6 +280,8 @@ extern "C" void ps_ctx_destroy(ps_ctx* c) {
         b->release();
     quotient_cache_free(c->qcache);
     if (c->up_scalars) ps_scalars_free(c->up_scalars);
+    for (ps_scalars* v : c->pv_scalars)
+        if (v) ps_scalars_free(v);
     if (c->g16_pa) ps_points_free(c->g16_pa);
     if (c->g16_pb) ps_points_free(c->g16_pb);
     if (c->g16_pc) ps_points_free(c->g16_pc);
@@ -365,6 +371,25 @@ static int upload_vector(ps_ctx* c, size_t n, ps_scalars** out) {
         c->up_cap = cap;
     }
     ps_scalars* s = c->up_scalars;
+    s->n = n;
+    s->first = 0;
+    s->max_bits = 255;
+    s->neg_small = false;
+    *out = s;
+    return PS_OK;
+}
+
+// The same for the provers' vectors (slot 0..3): handles owned by the context -- the caller must NOT free them; views made of them
+// (ps_scalars_slice) are freed as usual.  No sum is pending on a context between proofs, so the memory is free to reuse.
+static int prover_vector(ps_ctx* c, int slot, size_t n, ps_scalars** out) {
+    if (!c->pv_scalars[slot] || c->pv_cap[slot] < n) {
+        if (c->pv_scalars[slot]) { ps_scalars_free(c->pv_scalars[slot]); c->pv_scalars[slot] = nullptr; c->pv_cap[slot] = 0; }
+        const size_t cap = n + n / 8 + 64;
+        int rc = scalars_alloc(c, cap, &c->pv_scalars[slot]);
+        if (rc) return rc;
+        c->pv_cap[slot] = cap;
+    }
+    ps_scalars* s = c->pv_scalars[slot];
     s->n = n;
     s->first = 0;
     s->max_bits = 255;
